@@ -1,0 +1,151 @@
+/*
+ * sift_hip.h -- C ABI of the MI355X (gfx950) SIFT hot path.
+ *
+ * This is the drop-in boundary: the entry points are what the reference's
+ * SDSoC hardware-function calls would bind to.  Plain pointers and sizes only.
+ * All citations are into the reference tree (/root/reference/src).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative code otherwise
+ *     (SIFT_HIP_E*); sift_hip_last_error() gives the text of the last failure
+ *     on the calling thread.  The reference has no error channel (all `void`,
+ *     HW_SIFT.hpp:11-15); the C++ wrappers in include/HW_SIFT.hpp abort on a
+ *     non-zero code.
+ *   - a context owns one device, one stream and persistent device scratch for
+ *     `max_batch` frames (this replaces the per-call sds_alloc/sds_free of
+ *     HW_SIFT.cpp:23-24,44-45).  A context is not thread-safe; distinct
+ *     contexts are independent.
+ *   - frame size is a run-time parameter of the context (the reference fixes
+ *     WIDTH/HEIGHT at compile time, SIFTParameters.hpp:17-18).  width must be a
+ *     multiple of 4; width >= 4, height >= 1.
+ *   - outputs are always fully written: exactly max_keypoints keypoint slots
+ *     (zero padded, DetectKeypoints.cpp:428-436) and max_keypoints*72
+ *     descriptor words per frame.  Descriptors of padding slots are 0 (the
+ *     reference leaves them uninitialised, SIFT_Descriptor.cpp:194-196).
+ */
+#ifndef SIFT_HIP_H
+#define SIFT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIFT_HIP_MAX_KEYPOINTS 10000 /* MAX_KEYPOINTS, SIFTParameters.hpp:22 */
+#define SIFT_HIP_DESC_SIZE 72        /* DESC_SIZE,     SIFTParameters.hpp:26 */
+
+#define SIFT_HIP_OK 0
+#define SIFT_HIP_EINVAL (-1)  /* bad argument (null pointer, size, batch) */
+#define SIFT_HIP_EHIP (-2)    /* a HIP runtime call failed */
+#define SIFT_HIP_ENODEV (-3)  /* no usable gfx950 device / code object */
+
+/* Keypoint_t, SIFTParameters.hpp:79-85 (8 bytes) */
+typedef struct {
+    uint16_t x;        /* column */
+    uint16_t y;        /* row */
+    uint32_t contrast; /* |DoG2| at the keypoint */
+} sift_keypoint;
+
+/* Grad_t, SIFTParameters.hpp:88-92 (4 bytes) */
+typedef struct {
+    uint16_t angGrad; /* direction code 0..8 */
+    uint16_t magGrad; /* floor(sqrt(gx^2+gy^2)) */
+} sift_grad;
+
+typedef struct sift_hip_ctx sift_hip_ctx;
+
+/* ---- life cycle -------------------------------------------------------- */
+
+/* Replaces the sds_alloc calls of main.cpp:18-32 / HW_SIFT.cpp:23-24: creates
+ * the device-side state for frames of width x height on HIP device `device`.
+ * max_keypoints is the per-frame cap (reference: 10000); max_batch is the
+ * largest number of frames one call may carry (>= 1). */
+int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int max_keypoints, int max_batch);
+
+/* Replaces sds_free (main.cpp:214-217, HW_SIFT.cpp:44-45). */
+void sift_hip_destroy(sift_hip_ctx *ctx);
+
+/* Text of the last error on this thread ("" if none). */
+const char *sift_hip_last_error(void);
+
+/* Number of HIP devices visible (0 if none / runtime unusable). */
+int sift_hip_device_count(void);
+
+/* ---- host-buffer entry points (the reference's four hardware functions) -- */
+
+/* sift_detect_and_compute, HW_SIFT.hpp:11-15 / HW_SIFT.cpp:16-50.
+ * img: width*height bytes; kps: max_keypoints slots; desc: max_keypoints*72. */
+int sift_hip_detect_and_compute(sift_hip_ctx *ctx, const uint8_t *img, sift_keypoint *kps, uint32_t *desc,
+                                int contrastTh);
+
+/* sift_detect, DetectKeypoints.hpp:109-113 / DetectKeypoints.cpp:1073-1175.
+ * grad (width*height Grad_t) may be NULL when the caller does not want it. */
+int sift_hip_detect(sift_hip_ctx *ctx, const uint8_t *img, sift_grad *grad, sift_keypoint *kps, int contrastTh);
+
+/* compute_main_orientation, SIFT_Descriptor.hpp:12-14 / SIFT_Descriptor.cpp:18-103. */
+int sift_hip_main_orientation(sift_hip_ctx *ctx, const sift_grad *grad, const sift_keypoint *kps, uint8_t *ori);
+
+/* compute_descriptor, SIFT_Descriptor.hpp:59-62 / SIFT_Descriptor.cpp:419-478. */
+int sift_hip_descriptor(sift_hip_ctx *ctx, const sift_grad *grad, const sift_keypoint *kps, const uint8_t *ori,
+                        uint32_t *desc);
+
+/* The image loop of main.cpp:37-210 as one call: frame f of `nframes` goes to
+ * context f % nctx (one context per GPU), outputs land in the caller's
+ * per-frame slots kps[f*max_keypoints], desc[f*max_keypoints*72].  Frames are
+ * independent: no exchange between contexts. */
+int sift_hip_batch(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *imgs, int nframes,
+                   sift_keypoint *kps, uint32_t *desc, int contrastTh);
+
+/* ---- device-buffer entry points ------------------------------------------
+ * Same work with inputs and outputs already resident in this context's device
+ * memory (what the SDSoC data movers of DetectKeypoints.cpp:1054-1069 would
+ * otherwise copy).  d_imgs: nframes contiguous width*height frames;
+ * d_kps: nframes*max_keypoints; d_desc: nframes*max_keypoints*72;
+ * nframes <= max_batch.  `stream` is a hipStream_t (NULL = the context's own
+ * stream); the call only enqueues work, it does not synchronise.
+ * d_total (optional, may be NULL) receives per frame the uncapped survivor
+ * count (nKeypointsTotal, DetectKeypoints.cpp:380,405-406). */
+int sift_hip_detect_and_compute_dev(sift_hip_ctx *ctx, const uint8_t *d_imgs, int nframes, sift_keypoint *d_kps,
+                                    uint32_t *d_desc, uint32_t *d_total, int contrastTh, void *stream);
+
+/* sift_detect on device buffers; d_grad (nframes*width*height Grad_t) may be NULL. */
+int sift_hip_detect_dev(sift_hip_ctx *ctx, const uint8_t *d_imgs, int nframes, sift_grad *d_grad,
+                        sift_keypoint *d_kps, uint32_t *d_total, int contrastTh, void *stream);
+
+/* compute_main_orientation / compute_descriptor on device buffers (one frame's
+ * Grad_t plane per frame). */
+int sift_hip_main_orientation_dev(sift_hip_ctx *ctx, const sift_grad *d_grad, int nframes,
+                                  const sift_keypoint *d_kps, uint8_t *d_ori, void *stream);
+int sift_hip_descriptor_dev(sift_hip_ctx *ctx, const sift_grad *d_grad, int nframes, const sift_keypoint *d_kps,
+                            const uint8_t *d_ori, uint32_t *d_desc, void *stream);
+
+/* Block until everything this context enqueued has finished. */
+int sift_hip_sync(sift_hip_ctx *ctx);
+
+/* ---- introspection (tests, bench) ---------------------------------------- */
+
+/* Stage planes of frame `frame` of the LAST detect call on this context,
+ * copied to host.  Any pointer may be NULL.  g1/g2/g3: blurred planes
+ * (DetectKeypoints.cpp:1034-1037), width*height bytes each; cand: pre-cull
+ * candidate map |DoG2| (kpMap1, :207), u16 per pixel; eratio: Q15 eigen ratio
+ * at candidate pixels, 0x7fffffff elsewhere (the reference writes it for every
+ * pixel, :209; only candidate values are ever read, :728); surv: post-cull map
+ * before the border filter (kpMap2, :693). */
+int sift_hip_debug_planes(sift_hip_ctx *ctx, int frame, uint8_t *g1, uint8_t *g2, uint8_t *g3, uint16_t *cand,
+                          int32_t *eratio, uint16_t *surv);
+
+/* Kernel names in launch order and, when profiling is on, the HIP-event time
+ * of each kernel of the last *_dev / host call (ms).  Returns the stage count. */
+#define SIFT_HIP_NSTAGES 5
+int sift_hip_set_profiling(sift_hip_ctx *ctx, int on);
+int sift_hip_stage_ms(sift_hip_ctx *ctx, float ms[SIFT_HIP_NSTAGES]);
+const char *sift_hip_stage_name(int stage);
+
+/* Tuning knob: rows per thread strip of the blur kernel (0 = heuristic). */
+int sift_hip_set_blur_rows(sift_hip_ctx *ctx, int rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIFT_HIP_H */

@@ -1,0 +1,101 @@
+"""ctypes binding of the C ABI declared in include/sift_hip.h.
+
+Only plain pointers and sizes cross this boundary.  Loading fails loudly when
+the shared library is missing; nothing here falls back to a CPU path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "lib", "libsift_hip.so")
+
+MAX_KEYPOINTS = 10000   # SIFTParameters.hpp:22
+DESC_SIZE = 72          # SIFTParameters.hpp:26
+NSTAGES = 5
+
+# Keypoint_t (SIFTParameters.hpp:79-85) and Grad_t (:88-92)
+KP_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("contrast", "<u4")])
+GRAD_DTYPE = np.dtype([("ang", "<u2"), ("mag", "<u2")])
+
+# every symbol include/sift_hip.h declares (tests check the library exports all)
+EXPORTS = (
+    "sift_hip_create", "sift_hip_destroy", "sift_hip_last_error", "sift_hip_device_count",
+    "sift_hip_detect_and_compute", "sift_hip_detect", "sift_hip_main_orientation", "sift_hip_descriptor",
+    "sift_hip_batch", "sift_hip_detect_and_compute_dev", "sift_hip_detect_dev",
+    "sift_hip_main_orientation_dev", "sift_hip_descriptor_dev", "sift_hip_sync", "sift_hip_debug_planes",
+    "sift_hip_set_profiling", "sift_hip_stage_ms", "sift_hip_stage_name", "sift_hip_set_blur_rows",
+)
+
+
+class SiftHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("sift_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def library_path():
+    return _LIB
+
+
+def build_library(force=False):
+    """Compile sift_amd/csrc for gfx950 with hipcc (cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-s", "-C", src, "clean"])
+    subprocess.check_call(["make", "-s", "-C", src])
+    return _LIB
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise SiftHipError(-3, "libsift_hip.so not built (%s); run sift_amd.build_library()" % _LIB)
+    lib = C.CDLL(_LIB)
+    vp, i32 = C.c_void_p, C.c_int
+    lib.sift_hip_last_error.restype = C.c_char_p
+    lib.sift_hip_stage_name.restype = C.c_char_p
+    lib.sift_hip_stage_name.argtypes = [i32]
+    lib.sift_hip_destroy.restype = None
+    lib.sift_hip_destroy.argtypes = [vp]
+    lib.sift_hip_create.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32]
+    lib.sift_hip_detect_and_compute.argtypes = [vp, vp, vp, vp, i32]
+    lib.sift_hip_detect.argtypes = [vp, vp, vp, vp, i32]
+    lib.sift_hip_main_orientation.argtypes = [vp, vp, vp, vp]
+    lib.sift_hip_descriptor.argtypes = [vp, vp, vp, vp, vp]
+    lib.sift_hip_batch.argtypes = [C.POINTER(vp), i32, C.POINTER(vp), i32, vp, vp, i32]
+    lib.sift_hip_detect_and_compute_dev.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp]
+    lib.sift_hip_detect_dev.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp]
+    lib.sift_hip_main_orientation_dev.argtypes = [vp, vp, i32, vp, vp, vp]
+    lib.sift_hip_descriptor_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    lib.sift_hip_sync.argtypes = [vp]
+    lib.sift_hip_debug_planes.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
+    lib.sift_hip_set_profiling.argtypes = [vp, i32]
+    lib.sift_hip_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.sift_hip_set_blur_rows.argtypes = [vp, i32]
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc < 0:
+        raise SiftHipError(rc, load_library().sift_hip_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def _stage_names():
+    try:
+        lib = load_library()
+        return tuple(lib.sift_hip_stage_name(i).decode() for i in range(NSTAGES))
+    except Exception:
+        return ("k_blur", "k_detect", "k_cull", "k_emit", "k_describe")
+
+
+STAGE_NAMES = ("k_blur", "k_detect", "k_cull", "k_emit", "k_describe")

@@ -1,0 +1,536 @@
+// sift_hip.hip -- C ABI (include/sift_hip.h) over the gfx950 kernels.
+//
+// Host side of the drop-in boundary: context = device + stream + persistent
+// scratch; the four reference hardware functions (HW_SIFT.hpp:11-15,
+// DetectKeypoints.hpp:109-113, SIFT_Descriptor.hpp:12-14, :59-62) as host- and
+// device-buffer entry points.  No CPU fallback exists: without a HIP device
+// every entry point fails with SIFT_HIP_ENODEV / SIFT_HIP_EHIP.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <thread>
+
+#include "../../include/sift_hip.h"
+#include "blur_kernel.h"
+#include "detect_kernel.h"
+#include "compact_kernel.h"
+#include "describe_kernel.h"
+
+static_assert(sizeof(sift_keypoint) == 8 && sizeof(sift::kp_t) == 8, "Keypoint_t is 8 bytes");
+static_assert(sizeof(sift_grad) == 4, "Grad_t is 4 bytes");
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else
+        snprintf(buf, sizeof buf, "%s", what);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                 \
+    do {                                                              \
+        hipError_t e_ = (expr);                                       \
+        if (e_ != hipSuccess) return fail(SIFT_HIP_EHIP, #expr, e_); \
+    } while (0)
+
+enum { ST_BLUR = 0, ST_DETECT, ST_CULL, ST_EMIT, ST_DESCRIBE };
+const char *const kStageNames[SIFT_HIP_NSTAGES] = {"k_blur", "k_detect", "k_cull", "k_emit", "k_describe"};
+
+// Union-pixel table of the 71x71 descriptor window (see describe_kernel.h).
+std::vector<uint32_t> build_window_table()
+{
+    int owner[71][71][2];
+    int cnt[71][71];
+    memset(cnt, 0, sizeof cnt);
+    for (int n = 0; n < 9; n++)
+        for (int i = 0; i < 25; i++)
+            for (int j = SIFT_CIRCLE_LO[i]; j < SIFT_CIRCLE_HI[i]; j++) {
+                int y = SIFT_YSTART[n] + i, x = SIFT_XSTART[n] + j;
+                if (cnt[y][x] < 2) owner[y][x][cnt[y][x]] = n;
+                cnt[y][x]++;
+            }
+    std::vector<uint32_t> two, one;
+    for (int y = 0; y < 71; y++)
+        for (int x = 0; x < 71; x++) {
+            if (cnt[y][x] > 2) return {};   // would break Hist = sum Hin - Ov; checked in create()
+            if (cnt[y][x] == 2)
+                two.push_back((uint32_t)x | (uint32_t)y << 8 | (uint32_t)owner[y][x][0] << 16 | (uint32_t)owner[y][x][1] << 20);
+            else if (cnt[y][x] == 1)
+                one.push_back((uint32_t)x | (uint32_t)y << 8 | (uint32_t)owner[y][x][0] << 16 | 15u << 20);
+        }
+    while (two.size() % 64) two.push_back(15u << 16 | 15u << 20);   // keep the two-circle part wave aligned
+    two.insert(two.end(), one.begin(), one.end());
+    while (two.size() % 64) two.push_back(15u << 16 | 15u << 20);
+    return two;
+}
+
+}  // namespace
+
+struct sift_hip_ctx {
+    int device = 0, W = 0, H = 0, S = 0, max_kp = 0, max_batch = 0;
+    size_t npix = 0;
+    hipStream_t stream = nullptr;
+    // persistent scratch, max_batch frames each
+    uint8_t *d_img = nullptr;             // staging for host-buffer entry points
+    uint32_t *d_pyr = nullptr;            // src|G1|G2|G3 per pixel
+    unsigned long long *d_cand = nullptr, *d_surv = nullptr;   // [H][S] ballots
+    uint32_t *d_key = nullptr;            // (E<<8)|contrast at candidates
+    uint32_t *d_rowcount = nullptr;       // [H]
+    uint16_t *d_gradp = nullptr;          // (ang<<12)|mag
+    uint32_t *d_gradfull = nullptr;       // Grad_t staging (1 frame, lazily allocated)
+    sift::kp_t *d_kps = nullptr;          // staging for host-buffer entry points
+    uint32_t *d_desc = nullptr;
+    uint32_t *d_total = nullptr;
+    uint8_t *d_ori = nullptr;
+    uint32_t *d_tab = nullptr;
+    int ntab = 0;
+    int blur_rows = 0;
+    bool profiling = false;
+    hipEvent_t ev[SIFT_HIP_NSTAGES][2] = {};
+    bool ev_used[SIFT_HIP_NSTAGES] = {};
+    int last_frames = 0;
+};
+
+namespace {
+
+struct DevGuard {
+    int prev = -1;
+    explicit DevGuard(int dev) { hipGetDevice(&prev); if (prev != dev) hipSetDevice(dev); else prev = -1; }
+    ~DevGuard() { if (prev >= 0) hipSetDevice(prev); }
+};
+
+struct StageTimer {
+    sift_hip_ctx *c; int st; hipStream_t s;
+    StageTimer(sift_hip_ctx *c_, int st_, hipStream_t s_) : c(c_), st(st_), s(s_)
+    {
+        if (c->profiling) { hipEventRecord(c->ev[st][0], s); c->ev_used[st] = true; }
+    }
+    ~StageTimer() { if (c->profiling) hipEventRecord(c->ev[st][1], s); }
+};
+
+int pick_blur_rows(const sift_hip_ctx *c, int nframes)
+{
+    if (c->blur_rows > 0) return c->blur_rows;
+    // enough strips to give every SIMD of the chip two waves, not more than
+    // needed: short strips re-run the 18 warm-up rows more often
+    const int waves_per_strip = ((c->W / 4) + 63) / 64;
+    const long want_waves = 256L * 4 * 2;
+    long strips = (want_waves + (long)waves_per_strip * nframes - 1) / ((long)waves_per_strip * nframes);
+    if (strips < 1) strips = 1;
+    int rows = (int)((c->H + strips - 1) / strips);
+    if (rows < 16) rows = 16;
+    if (rows > c->H) rows = c->H;
+    return rows;
+}
+
+// blur -> detect -> cull -> emit on device-resident frames
+int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_gradfull, sift::kp_t *d_kps,
+               uint32_t *d_total, int th, hipStream_t s)
+{
+    const int W = c->W, H = c->H, S = c->S;
+    memset(c->ev_used, 0, sizeof c->ev_used);
+    c->last_frames = nframes;
+    {
+        StageTimer t(c, ST_BLUR, s);
+        const int rows = pick_blur_rows(c, nframes);
+        dim3 grid(((W / 4) + 255) / 256, (H + rows - 1) / rows, nframes);
+        // 64-thread blocks when a row has few dword columns, so small frames still spread over CUs
+        const int bs = (W / 4) >= 256 ? 256 : 64;
+        grid.x = ((W / 4) + bs - 1) / bs;
+        hipLaunchKernelGGL(sift::k_blur<true>, grid, dim3(bs), 0, s, d_imgs, c->d_pyr, W, H, rows);
+    }
+    {
+        StageTimer t(c, ST_DETECT, s);
+        const int rows = 16;
+        dim3 grid((W + 255) / 256, (H + rows - 1) / rows, nframes);
+        if (d_gradfull)
+            hipLaunchKernelGGL(sift::k_detect<true>, grid, dim3(256), 0, s, c->d_pyr, c->d_cand, c->d_key,
+                               c->d_gradp, d_gradfull, W, H, S, rows, th);
+        else
+            hipLaunchKernelGGL(sift::k_detect<false>, grid, dim3(256), 0, s, c->d_pyr, c->d_cand, c->d_key,
+                               c->d_gradp, (uint32_t *)nullptr, W, H, S, rows, th);
+    }
+    {
+        StageTimer t(c, ST_CULL, s);
+        dim3 grid((H + 3) / 4, nframes);
+        hipLaunchKernelGGL(sift::k_cull, grid, dim3(256), 0, s, c->d_cand, c->d_key, c->d_surv, c->d_rowcount, W, H, S);
+    }
+    {
+        StageTimer t(c, ST_EMIT, s);
+        dim3 grid((H + 1 + 3) / 4, nframes);
+        hipLaunchKernelGGL(sift::k_emit, grid, dim3(256), 0, s, c->d_surv, c->d_key, c->d_rowcount, d_kps, d_total,
+                           W, H, S, c->max_kp);
+    }
+    HIP_TRY(hipGetLastError());
+    return SIFT_HIP_OK;
+}
+
+template <int GFMT, int MODE>
+int run_describe(sift_hip_ctx *c, const void *d_grad, int nframes, const sift::kp_t *d_kps, const uint8_t *ori_in,
+                 uint8_t *ori_out, uint32_t *d_desc, hipStream_t s)
+{
+    StageTimer t(c, ST_DESCRIBE, s);
+    dim3 grid(c->max_kp, nframes);
+    hipLaunchKernelGGL((sift::k_describe<GFMT, MODE>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out, d_desc,
+                       c->d_tab, c->ntab, c->W, c->H, c->max_kp);
+    HIP_TRY(hipGetLastError());
+    return SIFT_HIP_OK;
+}
+
+int check_ctx(const sift_hip_ctx *c)
+{
+    if (!c) return fail(SIFT_HIP_EINVAL, "null context");
+    return SIFT_HIP_OK;
+}
+
+int ensure_gradfull(sift_hip_ctx *c)
+{
+    if (!c->d_gradfull) HIP_TRY(hipMalloc(&c->d_gradfull, c->npix * sizeof(uint32_t)));
+    return SIFT_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *sift_hip_last_error(void) { return g_err.c_str(); }
+
+int sift_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *sift_hip_stage_name(int stage)
+{
+    return (stage >= 0 && stage < SIFT_HIP_NSTAGES) ? kStageNames[stage] : "";
+}
+
+int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int max_keypoints, int max_batch)
+{
+    if (!out) return fail(SIFT_HIP_EINVAL, "out is null");
+    *out = nullptr;
+    if (width < 4 || (width & 3) || height < 1 || width > 65532 || height > 65535)
+        return fail(SIFT_HIP_EINVAL, "width must be a multiple of 4 in [4,65532], height in [1,65535]");
+    if (max_keypoints < 1 || max_batch < 1) return fail(SIFT_HIP_EINVAL, "max_keypoints and max_batch must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SIFT_HIP_ENODEV, "no HIP device");
+    if (device < 0 || device >= ndev) return fail(SIFT_HIP_EINVAL, "device index out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SIFT_HIP_ENODEV, "device is not gfx950 (the library carries gfx950 code only)");
+
+    std::vector<uint32_t> tab = build_window_table();
+    if (tab.empty()) return fail(SIFT_HIP_EINVAL, "circle tables overlap three-fold");
+
+    DevGuard g(device);
+    sift_hip_ctx *c = new sift_hip_ctx;
+    c->device = device; c->W = width; c->H = height; c->S = (width + 63) / 64;
+    c->max_kp = max_keypoints; c->max_batch = max_batch;
+    c->npix = (size_t)width * height;
+    const size_t B = (size_t)max_batch, np = c->npix, HS = (size_t)height * c->S;
+    hipError_t e = hipSuccess;
+    auto A = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    A((void **)&c->d_img, B * np);
+    A((void **)&c->d_pyr, B * np * 4);
+    A((void **)&c->d_cand, B * HS * 8);
+    A((void **)&c->d_surv, B * HS * 8);
+    A((void **)&c->d_key, B * np * 4);
+    A((void **)&c->d_rowcount, B * (size_t)height * 4);
+    A((void **)&c->d_gradp, B * np * 2);
+    A((void **)&c->d_kps, B * (size_t)max_keypoints * 8);
+    A((void **)&c->d_desc, B * (size_t)max_keypoints * 72 * 4);
+    A((void **)&c->d_total, B * 4);
+    A((void **)&c->d_ori, B * (size_t)max_keypoints);
+    A((void **)&c->d_tab, tab.size() * 4);
+    c->ntab = (int)tab.size();
+    if (e == hipSuccess) e = hipMemcpy(c->d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
+    for (int i = 0; i < SIFT_HIP_NSTAGES && e == hipSuccess; i++)
+        for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreate(&c->ev[i][k]);
+    if (e != hipSuccess) {
+        sift_hip_destroy(c);
+        return fail(SIFT_HIP_EHIP, "sift_hip_create", e);
+    }
+    *out = c;
+    return SIFT_HIP_OK;
+}
+
+void sift_hip_destroy(sift_hip_ctx *c)
+{
+    if (!c) return;
+    DevGuard g(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    void *ptrs[] = {c->d_img, c->d_pyr, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_gradp,
+                    c->d_gradfull, c->d_kps, c->d_desc, c->d_total, c->d_ori, c->d_tab};
+    for (void *p : ptrs) if (p) hipFree(p);
+    for (int i = 0; i < SIFT_HIP_NSTAGES; i++)
+        for (int k = 0; k < 2; k++) if (c->ev[i][k]) hipEventDestroy(c->ev[i][k]);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int sift_hip_sync(sift_hip_ctx *c)
+{
+    if (int r = check_ctx(c)) return r;
+    DevGuard g(c->device);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_set_profiling(sift_hip_ctx *c, int on)
+{
+    if (int r = check_ctx(c)) return r;
+    c->profiling = on != 0;
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_set_blur_rows(sift_hip_ctx *c, int rows)
+{
+    if (int r = check_ctx(c)) return r;
+    if (rows < 0) return fail(SIFT_HIP_EINVAL, "rows must be >= 0");
+    c->blur_rows = rows;
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_stage_ms(sift_hip_ctx *c, float ms[SIFT_HIP_NSTAGES])
+{
+    if (int r = check_ctx(c)) return r;
+    if (!ms) return fail(SIFT_HIP_EINVAL, "ms is null");
+    DevGuard g(c->device);
+    for (int i = 0; i < SIFT_HIP_NSTAGES; i++) {
+        ms[i] = -1.0f;
+        if (c->profiling && c->ev_used[i]) {
+            HIP_TRY(hipEventSynchronize(c->ev[i][1]));
+            HIP_TRY(hipEventElapsedTime(&ms[i], c->ev[i][0], c->ev[i][1]));
+        }
+    }
+    return SIFT_HIP_NSTAGES;
+}
+
+/* ---- device-buffer entry points ---------------------------------------- */
+
+int sift_hip_detect_dev(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, sift_grad *d_grad, sift_keypoint *d_kps,
+                        uint32_t *d_total, int contrastTh, void *stream)
+{
+    if (int r = check_ctx(c)) return r;
+    if (!d_imgs || !d_kps) return fail(SIFT_HIP_EINVAL, "null buffer");
+    if (nframes < 1 || nframes > c->max_batch) return fail(SIFT_HIP_EINVAL, "nframes outside [1, max_batch]");
+    DevGuard g(c->device);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return run_detect(c, d_imgs, nframes, (uint32_t *)d_grad, (sift::kp_t *)d_kps, d_total, contrastTh, s);
+}
+
+int sift_hip_detect_and_compute_dev(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, sift_keypoint *d_kps,
+                                    uint32_t *d_desc, uint32_t *d_total, int contrastTh, void *stream)
+{
+    if (int r = check_ctx(c)) return r;
+    if (!d_imgs || !d_kps || !d_desc) return fail(SIFT_HIP_EINVAL, "null buffer");
+    if (nframes < 1 || nframes > c->max_batch) return fail(SIFT_HIP_EINVAL, "nframes outside [1, max_batch]");
+    DevGuard g(c->device);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (int r = run_detect(c, d_imgs, nframes, nullptr, (sift::kp_t *)d_kps, d_total, contrastTh, s)) return r;
+    return run_describe<sift::GRAD_PACKED16, sift::DESC_FUSED>(c, c->d_gradp, nframes, (const sift::kp_t *)d_kps,
+                                                               nullptr, nullptr, d_desc, s);
+}
+
+int sift_hip_main_orientation_dev(sift_hip_ctx *c, const sift_grad *d_grad, int nframes, const sift_keypoint *d_kps,
+                                  uint8_t *d_ori, void *stream)
+{
+    if (int r = check_ctx(c)) return r;
+    if (!d_grad || !d_kps || !d_ori) return fail(SIFT_HIP_EINVAL, "null buffer");
+    if (nframes < 1 || nframes > c->max_batch) return fail(SIFT_HIP_EINVAL, "nframes outside [1, max_batch]");
+    DevGuard g(c->device);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    memset(c->ev_used, 0, sizeof c->ev_used);
+    return run_describe<sift::GRAD_FULL32, sift::DESC_ORI_ONLY>(c, d_grad, nframes, (const sift::kp_t *)d_kps, nullptr,
+                                                                d_ori, nullptr, s);
+}
+
+int sift_hip_descriptor_dev(sift_hip_ctx *c, const sift_grad *d_grad, int nframes, const sift_keypoint *d_kps,
+                            const uint8_t *d_ori, uint32_t *d_desc, void *stream)
+{
+    if (int r = check_ctx(c)) return r;
+    if (!d_grad || !d_kps || !d_ori || !d_desc) return fail(SIFT_HIP_EINVAL, "null buffer");
+    if (nframes < 1 || nframes > c->max_batch) return fail(SIFT_HIP_EINVAL, "nframes outside [1, max_batch]");
+    DevGuard g(c->device);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    memset(c->ev_used, 0, sizeof c->ev_used);
+    return run_describe<sift::GRAD_FULL32, sift::DESC_GIVEN_ORI>(c, d_grad, nframes, (const sift::kp_t *)d_kps, d_ori,
+                                                                 nullptr, d_desc, s);
+}
+
+/* ---- host-buffer entry points ------------------------------------------ */
+
+int sift_hip_detect_and_compute(sift_hip_ctx *c, const uint8_t *img, sift_keypoint *kps, uint32_t *desc, int contrastTh)
+{
+    if (int r = check_ctx(c)) return r;
+    if (!img || !kps || !desc) return fail(SIFT_HIP_EINVAL, "null buffer");
+    DevGuard g(c->device);
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->d_img, img, c->npix, hipMemcpyHostToDevice, s));
+    if (int r = sift_hip_detect_and_compute_dev(c, c->d_img, 1, (sift_keypoint *)c->d_kps, c->d_desc, c->d_total,
+                                                contrastTh, s))
+        return r;
+    HIP_TRY(hipMemcpyAsync(kps, c->d_kps, (size_t)c->max_kp * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(desc, c->d_desc, (size_t)c->max_kp * 72 * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_detect(sift_hip_ctx *c, const uint8_t *img, sift_grad *grad, sift_keypoint *kps, int contrastTh)
+{
+    if (int r = check_ctx(c)) return r;
+    if (!img || !kps) return fail(SIFT_HIP_EINVAL, "null buffer");
+    DevGuard g(c->device);
+    hipStream_t s = c->stream;
+    if (grad) if (int r = ensure_gradfull(c)) return r;
+    HIP_TRY(hipMemcpyAsync(c->d_img, img, c->npix, hipMemcpyHostToDevice, s));
+    if (int r = sift_hip_detect_dev(c, c->d_img, 1, grad ? (sift_grad *)c->d_gradfull : nullptr,
+                                    (sift_keypoint *)c->d_kps, c->d_total, contrastTh, s))
+        return r;
+    HIP_TRY(hipMemcpyAsync(kps, c->d_kps, (size_t)c->max_kp * 8, hipMemcpyDeviceToHost, s));
+    if (grad) HIP_TRY(hipMemcpyAsync(grad, c->d_gradfull, c->npix * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_main_orientation(sift_hip_ctx *c, const sift_grad *grad, const sift_keypoint *kps, uint8_t *ori)
+{
+    if (int r = check_ctx(c)) return r;
+    if (!grad || !kps || !ori) return fail(SIFT_HIP_EINVAL, "null buffer");
+    DevGuard g(c->device);
+    hipStream_t s = c->stream;
+    if (int r = ensure_gradfull(c)) return r;
+    HIP_TRY(hipMemcpyAsync(c->d_gradfull, grad, c->npix * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_kps, kps, (size_t)c->max_kp * 8, hipMemcpyHostToDevice, s));
+    if (int r = sift_hip_main_orientation_dev(c, (const sift_grad *)c->d_gradfull, 1, (const sift_keypoint *)c->d_kps,
+                                              c->d_ori, s))
+        return r;
+    HIP_TRY(hipMemcpyAsync(ori, c->d_ori, (size_t)c->max_kp, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_descriptor(sift_hip_ctx *c, const sift_grad *grad, const sift_keypoint *kps, const uint8_t *ori,
+                        uint32_t *desc)
+{
+    if (int r = check_ctx(c)) return r;
+    if (!grad || !kps || !ori || !desc) return fail(SIFT_HIP_EINVAL, "null buffer");
+    DevGuard g(c->device);
+    hipStream_t s = c->stream;
+    if (int r = ensure_gradfull(c)) return r;
+    HIP_TRY(hipMemcpyAsync(c->d_gradfull, grad, c->npix * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_kps, kps, (size_t)c->max_kp * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_ori, ori, (size_t)c->max_kp, hipMemcpyHostToDevice, s));
+    if (int r = sift_hip_descriptor_dev(c, (const sift_grad *)c->d_gradfull, 1, (const sift_keypoint *)c->d_kps,
+                                        c->d_ori, c->d_desc, s))
+        return r;
+    HIP_TRY(hipMemcpyAsync(desc, c->d_desc, (size_t)c->max_kp * 72 * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_batch(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *imgs, int nframes, sift_keypoint *kps,
+                   uint32_t *desc, int contrastTh)
+{
+    if (!ctxs || nctx < 1 || !imgs || nframes < 0 || !kps || !desc) return fail(SIFT_HIP_EINVAL, "bad argument");
+    for (int i = 0; i < nctx; i++) {
+        if (!ctxs[i]) return fail(SIFT_HIP_EINVAL, "null context");
+        if (ctxs[i]->W != ctxs[0]->W || ctxs[i]->H != ctxs[0]->H || ctxs[i]->max_kp != ctxs[0]->max_kp)
+            return fail(SIFT_HIP_EINVAL, "contexts differ in frame size or max_keypoints");
+    }
+    for (int f = 0; f < nframes; f++) if (!imgs[f]) return fail(SIFT_HIP_EINVAL, "null frame");
+    // one host thread per context (= per GPU); context i takes frames i, i+nctx, ...
+    // in chunks of its max_batch.  No exchange between contexts.
+    std::vector<int> rc(nctx, SIFT_HIP_OK);
+    std::vector<std::string> msg(nctx);
+    auto worker = [&](int ci) {
+        sift_hip_ctx *c = ctxs[ci];
+        DevGuard g(c->device);
+        hipStream_t s = c->stream;
+        const size_t np = c->npix, K = (size_t)c->max_kp;
+        std::vector<int> mine;
+        for (int f = ci; f < nframes; f += nctx) mine.push_back(f);
+        for (size_t b0 = 0; b0 < mine.size() && rc[ci] == SIFT_HIP_OK; b0 += (size_t)c->max_batch) {
+            const int nb = (int)std::min((size_t)c->max_batch, mine.size() - b0);
+            auto step = [&](hipError_t e, const char *what) {
+                if (e != hipSuccess && rc[ci] == SIFT_HIP_OK) { rc[ci] = SIFT_HIP_EHIP; msg[ci] = std::string(what) + ": " + hipGetErrorString(e); }
+            };
+            for (int k = 0; k < nb; k++)
+                step(hipMemcpyAsync(c->d_img + (size_t)k * np, imgs[mine[b0 + k]], np, hipMemcpyHostToDevice, s), "H2D frame");
+            if (rc[ci] == SIFT_HIP_OK) {
+                int r = sift_hip_detect_and_compute_dev(c, c->d_img, nb, (sift_keypoint *)c->d_kps, c->d_desc, c->d_total, contrastTh, s);
+                if (r) { rc[ci] = r; msg[ci] = g_err; }
+            }
+            for (int k = 0; k < nb && rc[ci] == SIFT_HIP_OK; k++) {
+                const size_t f = (size_t)mine[b0 + k];
+                step(hipMemcpyAsync(kps + f * K, c->d_kps + (size_t)k * K, K * 8, hipMemcpyDeviceToHost, s), "D2H keypoints");
+                step(hipMemcpyAsync(desc + f * K * 72, c->d_desc + (size_t)k * K * 72, K * 72 * 4, hipMemcpyDeviceToHost, s), "D2H descriptors");
+            }
+            step(hipStreamSynchronize(s), "sync");
+        }
+    };
+    if (nctx == 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < nctx; i++) th.emplace_back(worker, i);
+        for (auto &t : th) t.join();
+    }
+    for (int i = 0; i < nctx; i++)
+        if (rc[i] != SIFT_HIP_OK) return fail(rc[i], msg[i].c_str());
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_debug_planes(sift_hip_ctx *c, int frame, uint8_t *g1, uint8_t *g2, uint8_t *g3, uint16_t *cand,
+                          int32_t *eratio, uint16_t *surv)
+{
+    if (int r = check_ctx(c)) return r;
+    if (frame < 0 || frame >= c->last_frames) return fail(SIFT_HIP_EINVAL, "frame outside the last call's batch");
+    DevGuard g(c->device);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t np = c->npix;
+    if (g1 || g2 || g3) {
+        std::vector<uint32_t> pyr(np);
+        HIP_TRY(hipMemcpy(pyr.data(), c->d_pyr + (size_t)frame * np, np * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < np; i++) {
+            if (g1) g1[i] = (uint8_t)(pyr[i] >> 8);
+            if (g2) g2[i] = (uint8_t)(pyr[i] >> 16);
+            if (g3) g3[i] = (uint8_t)(pyr[i] >> 24);
+        }
+    }
+    if (cand || eratio || surv) {
+        uint16_t *d_c = nullptr, *d_s = nullptr;
+        int32_t *d_e = nullptr;
+        HIP_TRY(hipMalloc(&d_c, np * 2));
+        HIP_TRY(hipMalloc(&d_s, np * 2));
+        HIP_TRY(hipMalloc(&d_e, np * 4));
+        const size_t HS = (size_t)c->H * c->S;
+        dim3 grid((c->W + 255) / 256, c->H);
+        hipLaunchKernelGGL(sift::k_expand_maps, grid, dim3(256), 0, c->stream, c->d_cand + frame * HS,
+                           c->d_surv + frame * HS, c->d_key + (size_t)frame * np, d_c, d_e, d_s, c->W, c->H, c->S);
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess && cand) e = hipMemcpy(cand, d_c, np * 2, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && surv) e = hipMemcpy(surv, d_s, np * 2, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && eratio) e = hipMemcpy(eratio, d_e, np * 4, hipMemcpyDeviceToHost);
+        hipFree(d_c); hipFree(d_s); hipFree(d_e);
+        if (e != hipSuccess) return fail(SIFT_HIP_EHIP, "debug planes", e);
+    }
+    return SIFT_HIP_OK;
+}
+
+}  // extern "C"

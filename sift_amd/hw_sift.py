@@ -1,0 +1,194 @@
+"""Host-side mirror of the reference's entry points over the C ABI.
+
+Names and argument meaning follow HW_SIFT.hpp:11-15, DetectKeypoints.hpp:109-113
+and SIFT_Descriptor.hpp:12-14/:59-62; frame size is a property of the context
+instead of the compile-time WIDTH/HEIGHT of SIFTParameters.hpp:17-18.  Outputs
+have the reference's fixed shapes: MAX_KEYPOINTS keypoint slots (zero padded)
+and MAX_KEYPOINTS x 72 descriptor words.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import DESC_SIZE, GRAD_DTYPE, KP_DTYPE, MAX_KEYPOINTS, NSTAGES, check, load_library
+
+
+def _vp(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _dp(p):
+    """device pointer (int, or anything with data_ptr()) -> c_void_p"""
+    if p is None:
+        return None
+    if hasattr(p, "data_ptr"):
+        p = p.data_ptr()
+    return C.c_void_p(int(p))
+
+
+class SiftContext:
+    """One device + stream + persistent scratch (sift_hip_create)."""
+
+    def __init__(self, width, height, device=0, max_keypoints=MAX_KEYPOINTS, max_batch=1):
+        self._lib = load_library()
+        self.width, self.height = int(width), int(height)
+        self.max_keypoints, self.max_batch, self.device = int(max_keypoints), int(max_batch), int(device)
+        h = C.c_void_p()
+        check(self._lib.sift_hip_create(C.byref(h), self.device, self.width, self.height, self.max_keypoints,
+                                        self.max_batch))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sift_hip_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host-buffer entry points -------------------------------------------------
+    def _img(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        if img.shape != (self.height, self.width):
+            raise ValueError("image must be %dx%d uint8, got %r" % (self.height, self.width, img.shape))
+        return img
+
+    def _grad(self, grad):
+        grad = np.ascontiguousarray(grad, GRAD_DTYPE)
+        if grad.shape != (self.height, self.width):
+            raise ValueError("gradient plane must be %dx%d Grad_t" % (self.height, self.width))
+        return grad
+
+    def _kps(self, kps):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        if kps.shape != (self.max_keypoints,):
+            raise ValueError("keypoint array must have %d slots" % self.max_keypoints)
+        return kps
+
+    def sift_detect_and_compute(self, img, contrastTh=15):
+        img = self._img(img)
+        kps = np.empty(self.max_keypoints, KP_DTYPE)
+        desc = np.empty((self.max_keypoints, DESC_SIZE), np.uint32)
+        check(self._lib.sift_hip_detect_and_compute(self._h, _vp(img), _vp(kps), _vp(desc), int(contrastTh)))
+        return kps, desc
+
+    def sift_detect(self, img, contrastTh=15, want_grad=True):
+        img = self._img(img)
+        kps = np.empty(self.max_keypoints, KP_DTYPE)
+        grad = np.empty((self.height, self.width), GRAD_DTYPE) if want_grad else None
+        check(self._lib.sift_hip_detect(self._h, _vp(img), _vp(grad) if want_grad else None, _vp(kps),
+                                        int(contrastTh)))
+        return grad, kps
+
+    def compute_main_orientation(self, grad, kps):
+        grad, kps = self._grad(grad), self._kps(kps)
+        ori = np.empty(self.max_keypoints, np.uint8)
+        check(self._lib.sift_hip_main_orientation(self._h, _vp(grad), _vp(kps), _vp(ori)))
+        return ori
+
+    def compute_descriptor(self, grad, kps, ori):
+        grad, kps = self._grad(grad), self._kps(kps)
+        ori = np.ascontiguousarray(ori, np.uint8)
+        if ori.shape != (self.max_keypoints,):
+            raise ValueError("orientation array must have %d entries" % self.max_keypoints)
+        desc = np.empty((self.max_keypoints, DESC_SIZE), np.uint32)
+        check(self._lib.sift_hip_descriptor(self._h, _vp(grad), _vp(kps), _vp(ori), _vp(desc)))
+        return desc
+
+    # -- device-buffer entry points (pointers into this device's memory) -----------
+    def detect_and_compute_dev(self, d_imgs, nframes, d_kps, d_desc, d_total=None, contrastTh=15, stream=None):
+        check(self._lib.sift_hip_detect_and_compute_dev(self._h, _dp(d_imgs), int(nframes), _dp(d_kps), _dp(d_desc),
+                                                        _dp(d_total), int(contrastTh), _dp(stream)))
+
+    def detect_dev(self, d_imgs, nframes, d_grad, d_kps, d_total=None, contrastTh=15, stream=None):
+        check(self._lib.sift_hip_detect_dev(self._h, _dp(d_imgs), int(nframes), _dp(d_grad), _dp(d_kps),
+                                            _dp(d_total), int(contrastTh), _dp(stream)))
+
+    def main_orientation_dev(self, d_grad, nframes, d_kps, d_ori, stream=None):
+        check(self._lib.sift_hip_main_orientation_dev(self._h, _dp(d_grad), int(nframes), _dp(d_kps), _dp(d_ori),
+                                                      _dp(stream)))
+
+    def descriptor_dev(self, d_grad, nframes, d_kps, d_ori, d_desc, stream=None):
+        check(self._lib.sift_hip_descriptor_dev(self._h, _dp(d_grad), int(nframes), _dp(d_kps), _dp(d_ori),
+                                                _dp(d_desc), _dp(stream)))
+
+    def sync(self):
+        check(self._lib.sift_hip_sync(self._h))
+
+    # -- introspection ------------------------------------------------------------
+    def debug_planes(self, frame=0):
+        H, W = self.height, self.width
+        out = dict(g1=np.empty((H, W), np.uint8), g2=np.empty((H, W), np.uint8), g3=np.empty((H, W), np.uint8),
+                   cand=np.empty((H, W), np.uint16), eratio=np.empty((H, W), np.int32),
+                   surv=np.empty((H, W), np.uint16))
+        check(self._lib.sift_hip_debug_planes(self._h, int(frame), _vp(out["g1"]), _vp(out["g2"]), _vp(out["g3"]),
+                                              _vp(out["cand"]), _vp(out["eratio"]), _vp(out["surv"])))
+        return out
+
+    def set_profiling(self, on=True):
+        check(self._lib.sift_hip_set_profiling(self._h, int(bool(on))))
+
+    def set_blur_rows(self, rows):
+        check(self._lib.sift_hip_set_blur_rows(self._h, int(rows)))
+
+    def stage_ms(self):
+        ms = (C.c_float * NSTAGES)()
+        check(self._lib.sift_hip_stage_ms(self._h, ms))
+        return dict(zip(capi.STAGE_NAMES, [float(v) for v in ms]))
+
+
+def batch(contexts, imgs, contrastTh=15):
+    """sift_hip_batch: frame f -> contexts[f % len(contexts)]; returns (kps[n,K], desc[n,K,72])."""
+    lib = load_library()
+    c0 = contexts[0]
+    imgs = [c0._img(im) for im in imgs]
+    n, K = len(imgs), c0.max_keypoints
+    kps = np.empty((n, K), KP_DTYPE)
+    desc = np.empty((n, K, DESC_SIZE), np.uint32)
+    hs = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    ps = (C.c_void_p * max(n, 1))(*[im.ctypes.data for im in imgs])
+    check(lib.sift_hip_batch(hs, len(contexts), ps, n, _vp(kps), _vp(desc), int(contrastTh)))
+    return kps, desc
+
+
+# ---- module-level functions with the reference's names ---------------------------
+_default_ctx = {}
+
+
+def _ctx_for(shape, device=0):
+    key = (int(shape[0]), int(shape[1]), int(device))
+    if key not in _default_ctx:
+        _default_ctx[key] = SiftContext(key[1], key[0], device=key[2])
+    return _default_ctx[key]
+
+
+def sift_detect_and_compute(pSrcImage, contrastTh=15):
+    """HW_SIFT.cpp:16-50 -> (pKeypoints[10000], pDesc[10000,72])"""
+    pSrcImage = np.asarray(pSrcImage)
+    return _ctx_for(pSrcImage.shape).sift_detect_and_compute(pSrcImage, contrastTh)
+
+
+def sift_detect(pSrcImage, contrastTh=15):
+    """DetectKeypoints.cpp:1073-1175 -> (pGradients[H,W], pKeypoints[10000])"""
+    pSrcImage = np.asarray(pSrcImage)
+    return _ctx_for(pSrcImage.shape).sift_detect(pSrcImage, contrastTh)
+
+
+def compute_main_orientation(pGrad, pKeypoint):
+    """SIFT_Descriptor.cpp:18-103 -> pMainOrientation[10000]"""
+    return _ctx_for(np.asarray(pGrad).shape).compute_main_orientation(pGrad, pKeypoint)
+
+
+def compute_descriptor(pGrad, pKeypoint, pMainOrientation):
+    """SIFT_Descriptor.cpp:419-478 -> pDescriptorOut[10000,72]"""
+    return _ctx_for(np.asarray(pGrad).shape).compute_descriptor(pGrad, pKeypoint, pMainOrientation)
