@@ -135,11 +135,17 @@ int sift_hip_sync(sift_hip_ctx *ctx);
 int sift_hip_debug_planes(sift_hip_ctx *ctx, int frame, uint8_t *g1, uint8_t *g2, uint8_t *g3, uint16_t *cand,
                           int32_t *eratio, uint16_t *surv);
 
-/* Kernel names in launch order and, when profiling is on, the HIP-event time
- * of each kernel of the last *_dev / host call (ms).  Returns the stage count. */
+/* Per-kernel HIP-event timing.  sift_hip_set_profiling(ctx, nslots) keeps a ring
+ * of the last `nslots` calls (0 switches profiling off); every *_dev / host
+ * call then records one event pair per kernel on the stream it launches on.
+ * sift_hip_stage_ms(ctx, back, ms) waits for and returns the kernel times (ms,
+ * -1 for a kernel that call did not launch) of the call `back` calls before the
+ * most recent one (0 = most recent); its return value is the number of calls
+ * the ring holds.  sift_hip_stage_name gives the kernel names in launch order.
+ * This replaces the sds_clock_counter() bracket of main.cpp:63-77. */
 #define SIFT_HIP_NSTAGES 5
-int sift_hip_set_profiling(sift_hip_ctx *ctx, int on);
-int sift_hip_stage_ms(sift_hip_ctx *ctx, float ms[SIFT_HIP_NSTAGES]);
+int sift_hip_set_profiling(sift_hip_ctx *ctx, int nslots);
+int sift_hip_stage_ms(sift_hip_ctx *ctx, int back, float ms[SIFT_HIP_NSTAGES]);
 const char *sift_hip_stage_name(int stage);
 
 /* Tuning knob: rows per thread strip of the blur kernel (0 = heuristic). */

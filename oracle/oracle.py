@@ -144,3 +144,12 @@ def detect_and_compute(img, contrast_th=15):
     f.restype = C.c_int
     total = f(_p(img), C.c_int(W), C.c_int(H), _p(kps), _p(desc), C.c_int(contrast_th))
     return kps, desc, total
+
+
+def fnv1a(buf):
+    """64-bit FNV-1a of a contiguous numpy array / bytes, as a 16-digit hex string."""
+    a = np.frombuffer(buf, np.uint8) if not isinstance(buf, np.ndarray) else np.ascontiguousarray(buf).view(np.uint8).reshape(-1)
+    f = lib().orc_fnv1a
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_void_p, C.c_size_t]
+    return "%016x" % f(a.ctypes.data, a.size)

@@ -441,3 +441,12 @@ void orc_synth_frame(uint32_t seed, int W, int H, uint8_t *out)
             out[(size_t)y * W + x] = (uint8_t)(acc / 12);
         }
 }
+
+/* 64-bit FNV-1a, used by the tests to compare large outputs with the hashes in
+ * tests/golden/synth_expected.json (not reference code). */
+uint64_t orc_fnv1a(const uint8_t *p, size_t n)
+{
+    uint64_t h = 0xCBF29CE484222325ULL;
+    for (size_t i = 0; i < n; i++) h = (h ^ p[i]) * 0x100000001B3ULL;
+    return h;
+}

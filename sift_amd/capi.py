@@ -78,7 +78,7 @@ def load_library():
     lib.sift_hip_sync.argtypes = [vp]
     lib.sift_hip_debug_planes.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     lib.sift_hip_set_profiling.argtypes = [vp, i32]
-    lib.sift_hip_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.sift_hip_stage_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
     lib.sift_hip_set_blur_rows.argtypes = [vp, i32]
     _lib = lib
     return lib
@@ -88,14 +88,6 @@ def check(rc):
     if rc < 0:
         raise SiftHipError(rc, load_library().sift_hip_last_error().decode("utf-8", "replace"))
     return rc
-
-
-def _stage_names():
-    try:
-        lib = load_library()
-        return tuple(lib.sift_hip_stage_name(i).decode() for i in range(NSTAGES))
-    except Exception:
-        return ("k_blur", "k_detect", "k_cull", "k_emit", "k_describe")
 
 
 STAGE_NAMES = ("k_blur", "k_detect", "k_cull", "k_emit", "k_describe")

@@ -95,9 +95,11 @@ struct sift_hip_ctx {
     uint32_t *d_tab = nullptr;
     int ntab = 0;
     int blur_rows = 0;
-    bool profiling = false;
-    hipEvent_t ev[SIFT_HIP_NSTAGES][2] = {};
-    bool ev_used[SIFT_HIP_NSTAGES] = {};
+    // profiling: a ring of `nslots` calls, one HIP event pair per kernel of a call
+    struct ProfSlot { hipEvent_t ev[SIFT_HIP_NSTAGES][2] = {}; bool used[SIFT_HIP_NSTAGES] = {}; };
+    std::vector<ProfSlot> prof;
+    long ncalls = 0;                      // calls recorded since profiling was switched on
+    int cur = -1;                         // slot of the call being enqueued (-1: profiling off)
     int last_frames = 0;
 };
 
@@ -113,10 +115,19 @@ struct StageTimer {
     sift_hip_ctx *c; int st; hipStream_t s;
     StageTimer(sift_hip_ctx *c_, int st_, hipStream_t s_) : c(c_), st(st_), s(s_)
     {
-        if (c->profiling) { hipEventRecord(c->ev[st][0], s); c->ev_used[st] = true; }
+        if (c->cur >= 0) { hipEventRecord(c->prof[c->cur].ev[st][0], s); c->prof[c->cur].used[st] = true; }
     }
-    ~StageTimer() { if (c->profiling) hipEventRecord(c->ev[st][1], s); }
+    ~StageTimer() { if (c->cur >= 0) hipEventRecord(c->prof[c->cur].ev[st][1], s); }
 };
+
+// every entry point that enqueues kernels opens one profiling record
+void begin_call(sift_hip_ctx *c)
+{
+    if (c->prof.empty()) { c->cur = -1; return; }
+    c->cur = (int)(c->ncalls % (long)c->prof.size());
+    c->ncalls++;
+    memset(c->prof[c->cur].used, 0, sizeof c->prof[c->cur].used);
+}
 
 int pick_blur_rows(const sift_hip_ctx *c, int nframes)
 {
@@ -138,7 +149,6 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
                uint32_t *d_total, int th, hipStream_t s)
 {
     const int W = c->W, H = c->H, S = c->S;
-    memset(c->ev_used, 0, sizeof c->ev_used);
     c->last_frames = nframes;
     {
         StageTimer t(c, ST_BLUR, s);
@@ -258,8 +268,6 @@ int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int m
     A((void **)&c->d_tab, tab.size() * 4);
     c->ntab = (int)tab.size();
     if (e == hipSuccess) e = hipMemcpy(c->d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
-    for (int i = 0; i < SIFT_HIP_NSTAGES && e == hipSuccess; i++)
-        for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreate(&c->ev[i][k]);
     if (e != hipSuccess) {
         sift_hip_destroy(c);
         return fail(SIFT_HIP_EHIP, "sift_hip_create", e);
@@ -276,8 +284,9 @@ void sift_hip_destroy(sift_hip_ctx *c)
     void *ptrs[] = {c->d_img, c->d_pyr, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_gradp,
                     c->d_gradfull, c->d_kps, c->d_desc, c->d_total, c->d_ori, c->d_tab};
     for (void *p : ptrs) if (p) hipFree(p);
-    for (int i = 0; i < SIFT_HIP_NSTAGES; i++)
-        for (int k = 0; k < 2; k++) if (c->ev[i][k]) hipEventDestroy(c->ev[i][k]);
+    for (auto &ps : c->prof)
+        for (int i = 0; i < SIFT_HIP_NSTAGES; i++)
+            for (int k = 0; k < 2; k++) if (ps.ev[i][k]) hipEventDestroy(ps.ev[i][k]);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -290,10 +299,22 @@ int sift_hip_sync(sift_hip_ctx *c)
     return SIFT_HIP_OK;
 }
 
-int sift_hip_set_profiling(sift_hip_ctx *c, int on)
+int sift_hip_set_profiling(sift_hip_ctx *c, int nslots)
 {
     if (int r = check_ctx(c)) return r;
-    c->profiling = on != 0;
+    if (nslots < 0 || nslots > 4096) return fail(SIFT_HIP_EINVAL, "nslots outside [0, 4096]");
+    DevGuard g(c->device);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto &ps : c->prof)
+        for (int i = 0; i < SIFT_HIP_NSTAGES; i++)
+            for (int k = 0; k < 2; k++) if (ps.ev[i][k]) hipEventDestroy(ps.ev[i][k]);
+    c->prof.clear();
+    c->ncalls = 0;
+    c->cur = -1;
+    c->prof.resize((size_t)nslots);
+    for (auto &ps : c->prof)
+        for (int i = 0; i < SIFT_HIP_NSTAGES; i++)
+            for (int k = 0; k < 2; k++) HIP_TRY(hipEventCreate(&ps.ev[i][k]));
     return SIFT_HIP_OK;
 }
 
@@ -305,19 +326,22 @@ int sift_hip_set_blur_rows(sift_hip_ctx *c, int rows)
     return SIFT_HIP_OK;
 }
 
-int sift_hip_stage_ms(sift_hip_ctx *c, float ms[SIFT_HIP_NSTAGES])
+int sift_hip_stage_ms(sift_hip_ctx *c, int back, float ms[SIFT_HIP_NSTAGES])
 {
     if (int r = check_ctx(c)) return r;
     if (!ms) return fail(SIFT_HIP_EINVAL, "ms is null");
+    for (int i = 0; i < SIFT_HIP_NSTAGES; i++) ms[i] = -1.0f;
+    const long n = (long)c->prof.size();
+    const long have = c->ncalls < n ? c->ncalls : n;
+    if (back < 0 || back >= have) return fail(SIFT_HIP_EINVAL, "no profiling record that far back");
     DevGuard g(c->device);
-    for (int i = 0; i < SIFT_HIP_NSTAGES; i++) {
-        ms[i] = -1.0f;
-        if (c->profiling && c->ev_used[i]) {
-            HIP_TRY(hipEventSynchronize(c->ev[i][1]));
-            HIP_TRY(hipEventElapsedTime(&ms[i], c->ev[i][0], c->ev[i][1]));
+    const sift_hip_ctx::ProfSlot &ps = c->prof[(size_t)((c->ncalls - 1 - back) % n)];
+    for (int i = 0; i < SIFT_HIP_NSTAGES; i++)
+        if (ps.used[i]) {
+            HIP_TRY(hipEventSynchronize(ps.ev[i][1]));
+            HIP_TRY(hipEventElapsedTime(&ms[i], ps.ev[i][0], ps.ev[i][1]));
         }
-    }
-    return SIFT_HIP_NSTAGES;
+    return (int)have;
 }
 
 /* ---- device-buffer entry points ---------------------------------------- */
@@ -330,6 +354,7 @@ int sift_hip_detect_dev(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, sif
     if (nframes < 1 || nframes > c->max_batch) return fail(SIFT_HIP_EINVAL, "nframes outside [1, max_batch]");
     DevGuard g(c->device);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    begin_call(c);
     return run_detect(c, d_imgs, nframes, (uint32_t *)d_grad, (sift::kp_t *)d_kps, d_total, contrastTh, s);
 }
 
@@ -341,6 +366,7 @@ int sift_hip_detect_and_compute_dev(sift_hip_ctx *c, const uint8_t *d_imgs, int 
     if (nframes < 1 || nframes > c->max_batch) return fail(SIFT_HIP_EINVAL, "nframes outside [1, max_batch]");
     DevGuard g(c->device);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    begin_call(c);
     if (int r = run_detect(c, d_imgs, nframes, nullptr, (sift::kp_t *)d_kps, d_total, contrastTh, s)) return r;
     return run_describe<sift::GRAD_PACKED16, sift::DESC_FUSED>(c, c->d_gradp, nframes, (const sift::kp_t *)d_kps,
                                                                nullptr, nullptr, d_desc, s);
@@ -354,7 +380,7 @@ int sift_hip_main_orientation_dev(sift_hip_ctx *c, const sift_grad *d_grad, int 
     if (nframes < 1 || nframes > c->max_batch) return fail(SIFT_HIP_EINVAL, "nframes outside [1, max_batch]");
     DevGuard g(c->device);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    memset(c->ev_used, 0, sizeof c->ev_used);
+    begin_call(c);
     return run_describe<sift::GRAD_FULL32, sift::DESC_ORI_ONLY>(c, d_grad, nframes, (const sift::kp_t *)d_kps, nullptr,
                                                                 d_ori, nullptr, s);
 }
@@ -367,7 +393,7 @@ int sift_hip_descriptor_dev(sift_hip_ctx *c, const sift_grad *d_grad, int nframe
     if (nframes < 1 || nframes > c->max_batch) return fail(SIFT_HIP_EINVAL, "nframes outside [1, max_batch]");
     DevGuard g(c->device);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    memset(c->ev_used, 0, sizeof c->ev_used);
+    begin_call(c);
     return run_describe<sift::GRAD_FULL32, sift::DESC_GIVEN_ORI>(c, d_grad, nframes, (const sift::kp_t *)d_kps, d_ori,
                                                                  nullptr, d_desc, s);
 }

@@ -135,16 +135,24 @@ class SiftContext:
                                               _vp(out["cand"]), _vp(out["eratio"]), _vp(out["surv"])))
         return out
 
-    def set_profiling(self, on=True):
-        check(self._lib.sift_hip_set_profiling(self._h, int(bool(on))))
+    def set_profiling(self, nslots=1):
+        """keep HIP-event kernel times of the last `nslots` calls (0 = off)"""
+        check(self._lib.sift_hip_set_profiling(self._h, int(nslots)))
 
     def set_blur_rows(self, rows):
         check(self._lib.sift_hip_set_blur_rows(self._h, int(rows)))
 
-    def stage_ms(self):
+    def stage_ms(self, back=0):
+        """kernel times (ms) of the call `back` calls before the most recent one"""
         ms = (C.c_float * NSTAGES)()
-        check(self._lib.sift_hip_stage_ms(self._h, ms))
+        check(self._lib.sift_hip_stage_ms(self._h, int(back), ms))
         return dict(zip(capi.STAGE_NAMES, [float(v) for v in ms]))
+
+    def stage_ms_all(self):
+        """list of per-call dicts for every call the profiling ring holds, oldest first"""
+        ms = (C.c_float * NSTAGES)()
+        n = check(self._lib.sift_hip_stage_ms(self._h, 0, ms))
+        return [self.stage_ms(b) for b in range(n - 1, -1, -1)]
 
 
 def batch(contexts, imgs, contrastTh=15):

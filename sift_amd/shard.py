@@ -1,0 +1,74 @@
+"""Frame partitioning across GPUs: frames are independent units, so a batch
+of N frames is cut into contiguous ranges of ceil(N/G) per rank with no exchange step.  The
+only collectives are the timing barrier and the max-over-ranks of the elapsed time; they run
+on RCCL (backend "nccl") on GPUs and on gloo in the CPU tests."""
+import os
+
+
+def frame_range(nframes, rank, world):
+    """-> (first, last) of the contiguous range of frames rank `rank` of `world` owns"""
+    if world < 1 or not (0 <= rank < world) or nframes < 0:
+        raise ValueError("bad partition (%d frames, rank %d of %d)" % (nframes, rank, world))
+    per = (nframes + world - 1) // world
+    lo = min(nframes, rank * per)
+    return lo, min(nframes, lo + per)
+
+
+def frame_seeds(first_seed, per_rank, rank):
+    """weak scaling: rank r processes its own `per_rank` frames with distinct seeds"""
+    return [first_seed + rank * per_rank + i for i in range(per_rank)]
+
+
+class DistEnv:
+    """One process per GPU, launched by torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*)."""
+
+    def __init__(self, backend=None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.backend = backend
+        self._dist = None
+        self._device = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            self.backend = backend
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                self._device = torch.device("cuda", self.local_rank)
+            else:
+                self._device = torch.device("cpu")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if not dist.is_initialized():
+                if backend == "nccl":
+                    dist.init_process_group(backend, device_id=self._device)
+                else:
+                    dist.init_process_group(backend)
+            self._dist = dist
+
+    def barrier(self):
+        if self._dist is not None:
+            self._dist.barrier()
+
+    def max_over_ranks(self, value):
+        if self._dist is None:
+            return float(value)
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self._device)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, value):
+        if self._dist is None:
+            return int(value)
+        import torch
+        t = torch.tensor([int(value)], dtype=torch.int64, device=self._device)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        return int(t.item())
+
+    def close(self):
+        if self._dist is not None and self._dist.is_initialized():
+            self._dist.destroy_process_group()
+        self._dist = None

@@ -7,27 +7,30 @@ pixel    = (4 n_5 + 3 n_4 + 2 n_3 + 2 n_2 + 1 n_0) / 12
 import numpy as np
 
 _SCALES = ((5, 4), (4, 3), (3, 2), (2, 2), (0, 1))
-_M = np.uint64(0xFFFFFFFF)
 
 
 def _h32(x):
-    x = x & _M
-    x ^= x >> np.uint64(16)
-    x = (x * np.uint64(0x7FEB352D)) & _M
-    x ^= x >> np.uint64(15)
-    x = (x * np.uint64(0x846CA68B)) & _M
-    x ^= x >> np.uint64(16)
+    # uint32 array arithmetic wraps modulo 2^32, which is what the generator specifies
+    x = x ^ (x >> np.uint32(16))
+    x = x * np.uint32(0x7FEB352D)
+    x = x ^ (x >> np.uint32(15))
+    x = x * np.uint32(0x846CA68B)
+    x = x ^ (x >> np.uint32(16))
     return x
 
 
 def synth_frame(seed, width, height):
     """-> uint8 [height, width]"""
-    y = np.arange(height, dtype=np.uint64)[:, None]
-    x = np.arange(width, dtype=np.uint64)[None, :]
-    acc = np.zeros((height, width), np.uint64)
-    for s, w in _SCALES:
-        s64 = np.uint64(s)
-        inner = _h32(((y >> s64) * np.uint64(0x9E3779B1) + (x >> s64)) & _M)
-        n = _h32((np.uint64(seed & 0xFFFFFFFF) ^ inner ^ np.uint64((s * 0x85EBCA6B) & 0xFFFFFFFF))) & np.uint64(0xFF)
-        acc += np.uint64(w) * n
-    return (acc // np.uint64(12)).astype(np.uint8)
+    acc = np.zeros((height, width), np.uint32)
+    seed32 = np.uint32(seed & 0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        for s, w in _SCALES:
+            # the noise is constant on 2^s x 2^s cells: evaluate per cell, then repeat
+            cy = np.arange((height + (1 << s) - 1) >> s, dtype=np.uint32)[:, None]
+            cx = np.arange((width + (1 << s) - 1) >> s, dtype=np.uint32)[None, :]
+            inner = _h32(cy * np.uint32(0x9E3779B1) + cx)
+            n = _h32(seed32 ^ inner ^ np.uint32((s * 0x85EBCA6B) & 0xFFFFFFFF)) & np.uint32(0xFF)
+            if s:
+                n = np.repeat(np.repeat(n, 1 << s, axis=0), 1 << s, axis=1)[:height, :width]
+            acc += np.uint32(w) * n
+    return (acc // np.uint32(12)).astype(np.uint8)

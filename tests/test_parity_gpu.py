@@ -1,0 +1,233 @@
+"""HIP path vs the CPU oracle, through the C ABI (bit-exact: every quantity is integer).
+
+Sizes follow BASELINE.json's configs: im0 (cfg 0), 640x480 (cfg 1), 1920x1080 (cfg 2),
+3840x2160 with the 10,000 cap engaged (cfg 3), a batch of 1080p frames (cfg 4).
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def synth_expected(golden_dir):
+    with open(os.path.join(golden_dir, "synth_expected.json")) as f:
+        return json.load(f)
+
+
+def nvalid(kps):
+    return int((kps["contrast"] > 0).sum())
+
+
+def check_full(sift, orc, img, th=15, stages=True):
+    H, W = img.shape
+    with sift.SiftContext(W, H) as ctx:
+        kps, desc = ctx.sift_detect_and_compute(img, th)
+        rk, rd, total = orc.detect_and_compute(img, th)
+        n = nvalid(rk)
+        assert (kps == rk).all(), "keypoints differ"
+        assert (desc[:n] == rd[:n]).all(), "descriptors differ"
+        assert not desc[n:].any(), "padding descriptors must be zero"
+        if stages:
+            ref = orc.sift_detect(img, th, planes=True)
+            pl = ctx.debug_planes(0)
+            for a, b in (("g1", "g1"), ("g2", "g2"), ("g3", "g3"), ("cand", "kp1"), ("surv", "kp2")):
+                assert (pl[a] == ref[b]).all(), a
+            m = ref["kp1"] > 0
+            assert (pl["eratio"][m] == ref["eratio"][m]).all()
+            grad, kps2 = ctx.sift_detect(img, th)
+            assert (kps2 == rk).all()
+            assert (grad["ang"] == ref["grad"]["ang"]).all() and (grad["mag"] == ref["grad"]["mag"]).all()
+            ori = ctx.compute_main_orientation(ref["grad"], rk)
+            ro = orc.main_orientation(ref["grad"], rk)
+            assert (ori == ro).all()
+            d2 = ctx.compute_descriptor(ref["grad"], rk, ro)
+            assert (d2[:n] == rd[:n]).all() and not d2[n:].any()
+    return kps, desc, n, total
+
+
+def test_im0_reference_image(sift, orc, im0, golden_dir):
+    """cfg 0: the reference's own test image, against the committed fixture and the oracle."""
+    kps, desc, n, _ = check_full(sift, orc, im0)
+    z = np.load(os.path.join(golden_dir, "im0_expected.npz"))
+    assert n == 218 == len(z["kps"])
+    assert (kps[:n] == z["kps"]).all() and (desc[:n] == z["desc"]).all()
+
+
+@pytest.mark.parametrize("W,H,seed", [(640, 480, 1), (640, 480, 2), (256, 256, 3), (1920, 1080, 1), (1920, 1080, 2)])
+def test_synthetic_frames_all_stages(sift, orc, synth_expected, W, H, seed):
+    img = orc.synth_frame(seed, W, H)
+    kps, desc, n, total = check_full(sift, orc, img)
+    exp = synth_expected["%dx%d_s%d" % (W, H, seed)]
+    assert (n, total) == (exp["n"], exp["total"])
+    assert orc.fnv1a(kps) == exp["kps_fnv"] and orc.fnv1a(desc[:n]) == exp["desc_fnv"]
+
+
+def test_4k_cap_engaged(sift, orc, synth_expected):
+    """cfg 3: 42,412 survivors, the first 10,000 in raster order are kept (DetectKeypoints.cpp:409)."""
+    W, H = 3840, 2160
+    img = orc.synth_frame(1, W, H)
+    kps, desc, n, total = check_full(sift, orc, img, stages=False)
+    exp = synth_expected["3840x2160_s1"]
+    assert n == 10000 and total == exp["total"]
+    assert orc.fnv1a(kps) == exp["kps_fnv"] and orc.fnv1a(desc) == exp["desc_fnv"]
+    with sift.SiftContext(W, H) as ctx:
+        import torch
+        d_img = torch.from_numpy(img).cuda()
+        d_kps = torch.zeros(10000 * 8, dtype=torch.uint8, device="cuda")
+        d_desc = torch.zeros(10000 * 72, dtype=torch.int32, device="cuda")
+        d_tot = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ctx.detect_and_compute_dev(d_img, 1, d_kps, d_desc, d_tot)
+        ctx.sync()
+        assert int(d_tot.item()) == exp["total"]       # nKeypointsTotal is uncapped (:405-406)
+
+
+@pytest.mark.parametrize("W,H", [(4, 1), (8, 3), (64, 64), (144, 144), (148, 150), (200, 176), (324, 201),
+                                 (260, 1000), (1000, 148), (4100, 150)])
+def test_ragged_and_tiny_sizes(sift, orc, W, H):
+    """widths that are not multiples of 64/256, frames too small for any keypoint, thin frames"""
+    img = orc.synth_frame(11, W, H)
+    check_full(sift, orc, img)
+
+
+@pytest.mark.parametrize("fill", [0, 255, 37])
+def test_flat_frames(sift, orc, fill):
+    check_full(sift, orc, np.full((176, 192), fill, np.uint8))
+
+
+def test_extreme_frames(sift, orc):
+    rng = np.random.default_rng(5)
+    H, W = 240, 320
+    noise = rng.integers(0, 256, (H, W), dtype=np.uint8)                 # dense candidates, many cull ties
+    checker = ((np.add.outer(np.arange(H) // 5, np.arange(W) // 5) & 1) * 255).astype(np.uint8)
+    dots = np.zeros((H, W), np.uint8)
+    dots[::9, ::9] = 255                                                  # identical blobs: equal ratios kill each other
+    for img in (noise, checker, dots, 255 - dots):
+        check_full(sift, orc, img)
+
+
+@pytest.mark.parametrize("th", [0, 1, 5, 40, 255, 1000])
+def test_contrast_thresholds(sift, orc, th):
+    img = orc.synth_frame(4, 320, 240)
+    check_full(sift, orc, img, th=th, stages=False)
+
+
+def test_small_keypoint_cap(sift, orc):
+    """the cap applies in raster order and the total stays uncapped"""
+    W, H = 640, 480
+    img = orc.synth_frame(1, W, H)
+    ref = orc.sift_detect(img, max_kp=100)
+    with sift.SiftContext(W, H, max_keypoints=100) as ctx:
+        grad, kps = ctx.sift_detect(img)
+        assert (kps == ref["kps"]).all() and nvalid(kps) == 100
+        kps2, desc = ctx.sift_detect_and_compute(img)
+        ro = orc.main_orientation(ref["grad"], ref["kps"])
+        rd = orc.descriptor(ref["grad"], ref["kps"], ro)
+        assert (kps2 == ref["kps"]).all() and (desc == rd).all()
+
+
+def test_caller_supplied_keypoints_near_edges(sift, orc):
+    """compute_main_orientation / compute_descriptor take ANY keypoint list (SIFT_Descriptor.hpp:12-14,
+    :59-62); windows that leave the plane read {0,0} and padding slots (x==0 or y==0) give zeros."""
+    W, H = 320, 240
+    img = orc.synth_frame(8, W, H)
+    grad = orc.sift_detect(img)["grad"]
+    rng = np.random.default_rng(3)
+    kps = np.zeros(10000, sift.KP_DTYPE)
+    n = 600
+    kps["x"][:n] = rng.integers(0, W, n)
+    kps["y"][:n] = rng.integers(0, H, n)
+    kps["contrast"][:n] = rng.integers(1, 200, n)
+    kps[5] = (0, 17, 9)
+    kps[6] = (17, 0, 9)
+    kps[7] = (W - 1, H - 1, 9)
+    kps[8] = (1, 1, 9)
+    with sift.SiftContext(W, H) as ctx:
+        ori = ctx.compute_main_orientation(grad, kps)
+        ro = orc.main_orientation(grad, kps)
+        assert (ori == ro).all()
+        for o in (ro, rng.integers(0, 9, 10000).astype(np.uint8)):      # all rotation codes 0..8
+            d = ctx.compute_descriptor(grad, kps, o)
+            assert (d == orc.descriptor(grad, kps, o)).all()
+
+
+def test_batched_device_entry_points(sift, orc):
+    """cfg 4 shape: several frames per launch, inputs and outputs resident in HBM."""
+    import torch
+    W, H, B = 640, 480, 5
+    imgs = np.stack([orc.synth_frame(s, W, H) for s in range(20, 20 + B)])
+    K = 10000
+    with sift.SiftContext(W, H, max_batch=B) as ctx:
+        d_img = torch.from_numpy(imgs).cuda()
+        d_kps = torch.full((B, K, 2), -1, dtype=torch.int32, device="cuda")
+        d_desc = torch.full((B, K, 72), -1, dtype=torch.int32, device="cuda")
+        d_tot = torch.zeros(B, dtype=torch.int32, device="cuda")
+        d_grad = torch.zeros((B, H, W), dtype=torch.int32, device="cuda")
+        ctx.detect_and_compute_dev(d_img, B, d_kps, d_desc, d_tot)
+        ctx.sync()
+        kps = d_kps.cpu().numpy().view(sift.KP_DTYPE).reshape(B, K)
+        desc = d_desc.cpu().numpy().view(np.uint32)
+        d_kps2 = torch.zeros_like(d_kps)
+        ctx.detect_dev(d_img, B, d_grad, d_kps2, d_tot)
+        d_ori = torch.zeros((B, K), dtype=torch.uint8, device="cuda")
+        d_desc2 = torch.zeros_like(d_desc)
+        ctx.main_orientation_dev(d_grad, B, d_kps2, d_ori)
+        ctx.descriptor_dev(d_grad, B, d_kps2, d_ori, d_desc2)
+        ctx.sync()
+        assert torch.equal(d_kps, d_kps2) and torch.equal(d_desc, d_desc2)
+        grad = d_grad.cpu().numpy().view(sift.GRAD_DTYPE).reshape(B, H, W)
+        for b in range(B):
+            rk, rd, total = orc.detect_and_compute(imgs[b])
+            n = nvalid(rk)
+            assert (kps[b] == rk).all() and (desc[b, :n] == rd[:n]).all() and not desc[b, n:].any()
+            assert int(d_tot[b].item()) == total
+            rg = orc.sift_detect(imgs[b])["grad"]
+            assert (grad[b]["ang"] == rg["ang"]).all() and (grad[b]["mag"] == rg["mag"]).all()
+        with pytest.raises(sift.SiftHipError):
+            ctx.detect_and_compute_dev(d_img, B + 1, d_kps, d_desc)
+
+
+def test_host_batch_call(sift, orc):
+    """sift_hip_batch: the image loop of main.cpp:37-210, frames dealt over contexts."""
+    from sift_amd.hw_sift import batch
+    W, H = 320, 240
+    imgs = [orc.synth_frame(s, W, H) for s in range(40, 47)]
+    with sift.SiftContext(W, H, max_batch=2) as a, sift.SiftContext(W, H, max_batch=3) as b:
+        for ctxs in ([a], [a, b]):
+            kps, desc = batch(ctxs, imgs)
+            for f, im in enumerate(imgs):
+                rk, rd, _ = orc.detect_and_compute(im)
+                n = nvalid(rk)
+                assert (kps[f] == rk).all() and (desc[f, :n] == rd[:n]).all() and not desc[f, n:].any()
+
+
+def test_repeated_calls_are_idempotent(sift, orc):
+    """persistent scratch must not leak state between frames of different content"""
+    W, H = 640, 480
+    a, b = orc.synth_frame(1, W, H), np.zeros((H, W), np.uint8)
+    with sift.SiftContext(W, H) as ctx:
+        k1, d1 = ctx.sift_detect_and_compute(a)
+        k0, d0 = ctx.sift_detect_and_compute(b)
+        k2, d2 = ctx.sift_detect_and_compute(a)
+        assert not k0["contrast"].any() and not d0.any()
+        assert (k1 == k2).all() and (d1 == d2).all()
+
+
+def test_profiling_ring(sift, orc):
+    W, H = 640, 480
+    img = orc.synth_frame(1, W, H)
+    with sift.SiftContext(W, H) as ctx:
+        ctx.set_profiling(4)
+        for _ in range(6):
+            ctx.sift_detect_and_compute(img)
+        recs = ctx.stage_ms_all()
+        assert len(recs) == 4
+        for r in recs:
+            assert set(r) == set(sift.STAGE_NAMES) and all(0 < v < 50 for v in r.values())
+        ctx.set_profiling(0)
+        with pytest.raises(sift.SiftHipError):
+            ctx.stage_ms()

@@ -1,0 +1,55 @@
+"""Frame partitioning and the N>1 timing protocol, world_size 2 on gloo (CPU)."""
+import os
+import socket
+
+import pytest
+import torch.multiprocessing as mp
+
+from sift_amd.shard import DistEnv, frame_range, frame_seeds
+
+
+def test_frame_ranges_cover_every_frame_once():
+    for n in (0, 1, 7, 8, 40, 41, 1000):
+        for g in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(g):
+                lo, hi = frame_range(n, r, g)
+                assert 0 <= lo <= hi <= n and hi - lo <= (n + g - 1) // g
+                seen += list(range(lo, hi))
+            assert seen == list(range(n))
+    with pytest.raises(ValueError):
+        frame_range(10, 2, 2)
+
+
+def test_frame_seeds_disjoint():
+    s = [frame_seeds(1, 16, r) for r in range(8)]
+    flat = sum(s, [])
+    assert len(set(flat)) == 128 and flat[0] == 1
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env = DistEnv(backend="gloo")
+    lo, hi = frame_range(41, env.rank, env.world)
+    env.barrier()
+    t = env.max_over_ranks(1.0 + rank)          # the slowest rank sets the job time
+    total = env.sum_over_ranks(hi - lo)
+    q.put((rank, t, total))
+    env.close()
+
+
+def test_two_rank_protocol_on_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert out == [(0, 2.0, 41), (1, 2.0, 41)]
