@@ -13,39 +13,71 @@
 //        orientation histogram  Hist[a] = sum_n Hin[n][a] - Ov[a]      (exact integers)
 // and each of the 3809 union pixels of the 71x71 window is loaded once.
 //
-// A host-built table lists the union pixels (those in two circles first):
-//   entry = dx | dy<<8 | c1<<16 | c2<<20          (c = 15: none)
-// Lane l accumulates into its own LDS column hist[row][l] (bank = lane, no
-// conflicts, ds_add_u32 without return); rows are circle*8 + (ang-1), then 8
-// rows for Ov.  Codes outside 1..8 are dropped (code 0 is accumulated and then
-// discarded by the reference, :245-252).  The 80 row sums are then read with a
-// per-lane skew so that the 64 lanes hit 64 different banks.
+// A host-built table lists the union pixels in raster order, those in two
+// circles first (part A, n2 entries, padded to a multiple of 64), then the
+// rest (part B).  One entry is two dwords:
+//   lo = (dy*W + dx) * 2          byte offset of the pixel in a 2-byte plane
+//   hi = c1 << 9 | c2 << 25       circle ids, pre-shifted to LDS row offsets
+// Consecutive lanes take consecutive entries, i.e. neighbouring pixels of a
+// window row, so one gather instruction touches 2-3 rows of 142 bytes.
+//
+// Lanes l and l+32 accumulate into LDS column l of hist[row][32] (bank =
+// column: no conflicts inside a half wave; ds_add_u32 without return).
+//   * internal gradient format (k_detect's 2-byte plane): one word is
+//     mag | a << 9 with a = code-1, and 0 for code 0, so every pixel is added
+//     without a test (code 0 is accumulated and then discarded by the
+//     reference, :245-252).  Two direction bins share a dword as 16-bit
+//     halves: row = circle*4 + (a>>1), half = a&1 (40 rows, 5 KB per wave).
+//     A half holds at most 2 lanes x 61 pixels x 360 < 2^16.
+//   * caller-supplied Grad_t planes (the stand-alone entry points): a bin is a
+//     full dword, row = circle*8 + a (80 rows); codes outside 1..8 are dropped.
+// The column sums are formed with 16-byte LDS reads (lane -> row i*8 + lane/8,
+// columns 4*(lane%8)..+3) and an 8-lane DPP reduction.
 //
 // The gradient plane is addressed linearly like the reference does
 // (pGrad[y*WIDTH + x - 35 + col], :64/:204); indices outside the plane read
-// {0,0} (the reference would read out of bounds).
+// {0,0} (the reference would read out of bounds).  Keypoints whose window lies
+// inside the plane -- all that sift_detect emits -- take a path without checks.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "compact_kernel.h"
+#include "detect_kernel.h"
 
 namespace sift {
 
 enum { DESC_FUSED = 0, DESC_ORI_ONLY = 1, DESC_GIVEN_ORI = 2 };
 enum { GRAD_PACKED16 = 0, GRAD_FULL32 = 1 };
 
-constexpr int DESC_ROWS = 80;   // 72 circle bins + 8 overlap bins
+constexpr int DESC_MAX_MAG_PACKED = 360;     // floor(sqrt(2*255^2)), the largest k_detect can produce
+constexpr int DESC_UNROLL = 4;               // table entries a lane has in flight
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t x)   // 0 where the source lies outside the row of 16
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)   // v_pk_add_u16
+{
+    us2 r = __builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b);
+    return __builtin_bit_cast(uint32_t, r);
+}
 
 // grid: x = max_kp keypoints, y = frames; block = 64 (one wave)
 template <int GFMT, int MODE>
 __global__ __launch_bounds__(64) void k_describe(const void *__restrict__ gradv, const kp_t *__restrict__ kps,
                                                  const uint8_t *__restrict__ ori_in, uint8_t *__restrict__ ori_out,
-                                                 uint32_t *__restrict__ desc, const uint32_t *__restrict__ tab,
-                                                 int ntab, int W, int H, int max_kp)
+                                                 uint32_t *__restrict__ desc, const uint2 *__restrict__ tab,
+                                                 int n2, int n2pad, int ntab, int W, int H, int max_kp)
 {
-    __shared__ uint32_t hist[DESC_ROWS][64];
-    __shared__ uint32_t fin[DESC_ROWS];
-    __shared__ uint32_t s_m;
+    constexpr bool PACK = GFMT == GRAD_PACKED16;
+    constexpr int ROWS = PACK ? 40 : 80;
+    constexpr int U = DESC_UNROLL;
+    __shared__ __align__(16) uint32_t hist[ROWS][32];
+    __shared__ uint32_t fin[80];
 
     const int lane = threadIdx.x;
     const size_t slot = (size_t)blockIdx.y * max_kp + blockIdx.x;
@@ -62,77 +94,131 @@ __global__ __launch_bounds__(64) void k_describe(const void *__restrict__ gradv,
         return;
     }
 
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(&hist[0][0]);
 #pragma unroll
-    for (int r = 0; r < DESC_ROWS; r++) hist[r][lane] = 0;
-    // same-lane LDS accesses are ordered; no barrier needed before the adds
+        for (int i = 0; i < ROWS * 32 / 4 / 64; i++) z[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
 
     const long npix = (long)W * H;
-    const size_t fpix = (size_t)blockIdx.y * (size_t)npix;
     const long origin = (long)(py - 35) * W + (px - 35);
-    for (int t = lane; t < ntab; t += 64) {
-        const uint32_t e = tab[t];
-        const int dx = e & 0xff, dy = (e >> 8) & 0xff;
-        const int c1 = (e >> 16) & 15, c2 = (e >> 20) & 15;
-        const long idx = origin + (long)dy * W + dx;
-        int ang = 0;
-        uint32_t mag = 0;
-        if (idx >= 0 && idx < npix) {
-            if (GFMT == GRAD_PACKED16) {
-                const uint32_t g = reinterpret_cast<const uint16_t *>(gradv)[fpix + idx];
-                ang = g >> 12;
-                mag = g & 0xfffu;
-            } else {
-                const uint32_t g = reinterpret_cast<const uint32_t *>(gradv)[fpix + idx];
-                ang = g & 0xffffu;
-                mag = g >> 16;
-            }
-        }
-        if (ang >= 1 && ang <= 8 && c1 != 15) {
-            atomicAdd(&hist[c1 * 8 + ang - 1][lane], mag);
-            if (c2 != 15) {
-                atomicAdd(&hist[c2 * 8 + ang - 1][lane], mag);
-                atomicAdd(&hist[72 + ang - 1][lane], mag);
-            }
-        }
-    }
-    __syncthreads();
+    const char *__restrict__ gplane = reinterpret_cast<const char *>(gradv) +
+                                      ((size_t)blockIdx.y * (size_t)npix) * (PACK ? 2 : 4);
+    const uint32_t col4 = (uint32_t)(lane & 31) * 4u;
+    char *const hbase = reinterpret_cast<char *>(&hist[0][0]);
 
-    // row sums: lane l takes rows l and l+64, reading column (c+l)&63 at step c
-    {
-        uint32_t s0 = 0, s1 = 0;
-        const bool second = lane + 64 < DESC_ROWS;
-#pragma unroll 8
-        for (int c = 0; c < 64; c++) {
-            const int col = (c + lane) & 63;
-            s0 += hist[lane][col];
-            if (second) s1 += hist[lane + 64][col];
-        }
-        fin[lane] = s0;
-        if (second) fin[lane + 64] = s1;
-    }
-    __syncthreads();
-
-    // main orientation (:110-126): first bin 1..8 with the strictly largest value
-    if (lane == 0) {
-        uint32_t m = 0;
-        if (MODE == DESC_GIVEN_ORI) {
-            m = ori_in[slot];
+    auto gather = [&](auto chk, uint32_t off2, bool live) -> uint32_t {
+        long idx = origin + (long)(off2 >> 1);
+        bool ok = live;
+        if constexpr (decltype(chk)::value) ok = ok && idx >= 0 && idx < npix;
+        idx = ok ? idx : (decltype(chk)::value ? 0 : origin);
+        uint32_t g;
+        if constexpr (PACK) g = *reinterpret_cast<const uint16_t *>(gplane + idx * 2);
+        else g = *reinterpret_cast<const uint32_t *>(gplane + idx * 4);
+        return ok ? g : 0u;
+    };
+    auto add = [&](uint32_t byteofs, uint32_t v) {
+        atomicAdd(reinterpret_cast<uint32_t *>(hbase + byteofs), v);
+    };
+    auto accumulate = [&](auto two, uint32_t hi, uint32_t g) {
+        if constexpr (PACK) {
+            // g = mag | a << 9 (0 for code 0): value into half a&1 of row circle*4 + (a>>1)
+            const uint32_t v = (g & 0x1ffu) << ((g >> 5) & 16u);
+            const uint32_t rl = ((g >> 3) & 0x180u) | col4;            // (a>>1) * 128 + column
+            add(((hi & 0x1e00u)) + rl, v);                             // circle * 512
+            if constexpr (decltype(two)::value) {
+                add(((hi >> 16) & 0x1e00u) + rl, v);
+                add(36u * 128u + rl, v);
+            }
         } else {
-            int best = 0;
-            for (int a = 0; a < 8; a++) {
-                int v = -(int)fin[72 + a];
-                for (int n = 0; n < 9; n++) v += (int)fin[n * 8 + a];
-                if (v > best) { best = v; m = (uint32_t)(a + 1); }
+            const uint32_t a = (g & 0xffffu) - 1u;
+            const uint32_t v = a < 8u ? (g >> 16) : 0u;
+            const uint32_t rl = ((a & 7u) << 7) | col4;
+            add(((hi & 0x1e00u) << 1) + rl, v);                        // circle * 1024
+            if constexpr (decltype(two)::value) {
+                add((((hi >> 16) & 0x1e00u) << 1) + rl, v);
+                add(72u * 128u + rl, v);
             }
-            if (ori_out) ori_out[slot] = (uint8_t)m;
         }
-        s_m = m;
+    };
+    // entries [begin, end): lane takes begin + lane, + 64, ...; U in flight
+    auto part = [&](auto chk, auto two, int begin, int end) {
+        for (int t0 = begin; t0 < end; t0 += 64 * U) {
+            uint2 e[U];
+            uint32_t g[U];
+            bool live[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int t = t0 + u * 64 + lane;
+                live[u] = t < end;
+                e[u] = tab[live[u] ? t : begin];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) g[u] = gather(chk, e[u].x, live[u]);
+#pragma unroll
+            for (int u = 0; u < U; u++) accumulate(two, e[u].y, g[u]);
+        }
+    };
+    auto sweep = [&](auto chk) {
+        part(chk, std::true_type{}, 0, n2);
+        part(chk, std::false_type{}, n2pad, ntab);
+    };
+    // the window is rows py-35..py+35 at columns px-35..px+35 of a linearly addressed plane
+    if (origin >= 0 && origin + 70L * W + 70 < npix)
+        sweep(std::false_type{});
+    else
+        sweep(std::true_type{});
+    __syncthreads();
+
+    // column sums -> fin[bin], bin = circle*8 + a (72..79: overlap)
+    {
+        const int cg = lane & 7, rsub = lane >> 3;
+#pragma unroll
+        for (int i = 0; i < ROWS / 8; i++) {
+            const int row = i * 8 + rsub;
+            const uint4 q = *reinterpret_cast<const uint4 *>(&hist[row][cg * 4]);
+            if constexpr (PACK) {
+                // 16-bit halves: 4 columns x K pixels x 360 stays below 2^16 (K = pixels of one circle
+                // that fall to one column, 27 for the reference's tables; checked on the host);
+                // widen after that
+                const uint32_t p = pk_add(pk_add(q.x, q.y), pk_add(q.z, q.w));
+                uint32_t lo = p & 0xffffu, hi = p >> 16;
+                lo += dpp_mov<0x111>(lo); hi += dpp_mov<0x111>(hi);    // row_shr:1
+                lo += dpp_mov<0x112>(lo); hi += dpp_mov<0x112>(hi);    // row_shr:2
+                lo += dpp_mov<0x114>(lo); hi += dpp_mov<0x114>(hi);    // row_shr:4
+                if (cg == 7) { fin[row * 2] = lo; fin[row * 2 + 1] = hi; }
+            } else {
+                uint32_t s = q.x + q.y + q.z + q.w;
+                s += dpp_mov<0x111>(s);
+                s += dpp_mov<0x112>(s);
+                s += dpp_mov<0x114>(s);
+                if (cg == 7) fin[row] = s;
+            }
+        }
     }
     __syncthreads();
+
+    // main orientation (:110-126): first bin 1..8 with the strictly largest value, 0 if none > 0
+    uint32_t m;
+    if (MODE == DESC_GIVEN_ORI) {
+        m = ori_in[slot];
+    } else {
+        const int a = lane & 7;
+        uint32_t v = 0u - fin[72 + a];
+#pragma unroll
+        for (int n = 0; n < 9; n++) v += fin[n * 8 + a];
+        // (int)v > 0 is the reference's test; the key orders by value, then by smaller a
+        uint32_t key = ((int)v > 0) ? ((v << 3) | (uint32_t)(7 - a)) : 0u;
+        key = max(key, (uint32_t)__shfl_xor((int)key, 1));
+        key = max(key, (uint32_t)__shfl_xor((int)key, 2));
+        key = max(key, (uint32_t)__shfl_xor((int)key, 4));
+        m = key ? 8u - (key & 7u) : 0u;
+        if (ori_out && lane == 0) ori_out[slot] = (uint8_t)m;
+    }
     if (MODE == DESC_ORI_ONLY) return;
 
     // rotation (:346-393): out[c][j] = Hin[c<8 ? (c+m)&7 : 8][(j+m)&7]
-    const uint32_t m = s_m;
     {
         const int c = lane >> 3, j = lane & 7;       // circles 0..7
         out[lane] = fin[((c + m) & 7) * 8 + ((j + m) & 7)];

@@ -15,7 +15,7 @@
 // Outputs per frame
 //   candmask[y][seg]  u64 ballot of pre-cull candidates (kpMap1 != 0)
 //   keyplane[y][x]    u32, written ONLY at candidates: (E_q15 << 8) | |D2|
-//   gradp[y][x]       u16 (ang << 12) | mag          (internal, 2 B/pixel)
+//   gradp[y][x]       u16 mag | (ang-1) << 9, 0 for ang 0  (internal, 2 B/pixel; describe_kernel.h)
 //   gradfull[y][x]    Grad_t {ang, mag}              (optional, sift_detect API)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -45,6 +45,13 @@ __device__ __forceinline__ int edge_ratio_q15(int L, int R, int U, int Dn, int U
     const float v = r * 32768.0f;
     const float fl = floorf(v);
     return (int)fl + ((v - fl) > 0.5f ? 1 : 0);
+}
+
+// internal 2-byte gradient word (written by k_detect, read by k_describe): mag | (code-1) << 9,
+// and 0 for code 0, whose magnitude never reaches a descriptor bin
+__device__ __forceinline__ uint32_t gradp_pack(int ang, int mag)
+{
+    return ang ? ((uint32_t)mag | ((uint32_t)(ang - 1) << 9)) : 0u;
 }
 
 // ComputeGradientKernel (:1186-1225)
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(256) void k_detect(const uint32_t *__restrict__ pyr
         if (xin) {
             int ang, mag;
             grad_code(pyr_g2(r1[2]) - pyr_g2(r1[0]), pyr_g2(r2[1]) - pyr_g2(r0[1]), ang, mag);
-            gradp[fpix + (size_t)y * W + x] = (uint16_t)((ang << 12) | mag);
+            gradp[fpix + (size_t)y * W + x] = (uint16_t)gradp_pack(ang, mag);
             if constexpr (FULLGRAD) gradfull[fpix + (size_t)y * W + x] = (uint32_t)ang | ((uint32_t)mag << 16);
         }
 #pragma unroll

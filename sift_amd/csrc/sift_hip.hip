@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 #include <thread>
+#include <algorithm>
 
 #include "../../include/sift_hip.h"
 #include "blur_kernel.h"
@@ -46,8 +47,11 @@ int fail(int code, const char *what, hipError_t e = hipSuccess)
 enum { ST_BLUR = 0, ST_DETECT, ST_CULL, ST_EMIT, ST_DESCRIBE };
 const char *const kStageNames[SIFT_HIP_NSTAGES] = {"k_blur", "k_detect", "k_cull", "k_emit", "k_describe"};
 
-// Union-pixel table of the 71x71 descriptor window (see describe_kernel.h).
-std::vector<uint32_t> build_window_table()
+// Union-pixel table of the 71x71 descriptor window for frames `W` wide (see
+// describe_kernel.h): two-circle pixels first (n2, padded to n2pad), then the rest.
+// kmax = the most pixels of one circle (or of the overlap set) that fall to one lane.
+struct WindowTable { std::vector<uint2> e; int n2 = 0, n2pad = 0, kmax = 0; };
+WindowTable build_window_table(int W)
 {
     int owner[71][71][2];
     int cnt[71][71];
@@ -59,19 +63,33 @@ std::vector<uint32_t> build_window_table()
                 if (cnt[y][x] < 2) owner[y][x][cnt[y][x]] = n;
                 cnt[y][x]++;
             }
-    std::vector<uint32_t> two, one;
+    WindowTable t;
+    std::vector<uint2> one;
     for (int y = 0; y < 71; y++)
         for (int x = 0; x < 71; x++) {
-            if (cnt[y][x] > 2) return {};   // would break Hist = sum Hin - Ov; checked in create()
+            if (cnt[y][x] > 2) return WindowTable{};   // would break Hist = sum Hin - Ov; checked in create()
+            const uint32_t off2 = (uint32_t)(y * W + x) * 2u;
             if (cnt[y][x] == 2)
-                two.push_back((uint32_t)x | (uint32_t)y << 8 | (uint32_t)owner[y][x][0] << 16 | (uint32_t)owner[y][x][1] << 20);
+                t.e.push_back(make_uint2(off2, (uint32_t)owner[y][x][0] << 9 | (uint32_t)owner[y][x][1] << 25));
             else if (cnt[y][x] == 1)
-                one.push_back((uint32_t)x | (uint32_t)y << 8 | (uint32_t)owner[y][x][0] << 16 | 15u << 20);
+                one.push_back(make_uint2(off2, (uint32_t)owner[y][x][0] << 9));
         }
-    while (two.size() % 64) two.push_back(15u << 16 | 15u << 20);   // keep the two-circle part wave aligned
-    two.insert(two.end(), one.begin(), one.end());
-    while (two.size() % 64) two.push_back(15u << 16 | 15u << 20);
-    return two;
+    t.n2 = (int)t.e.size();
+    while (t.e.size() % 64) t.e.push_back(make_uint2(0, 0));   // never read: the loops stop at n2
+    t.n2pad = (int)t.e.size();
+    t.e.insert(t.e.end(), one.begin(), one.end());
+    // lanes l and l+32 share LDS column l: count per (column, circle | overlap)
+    int k[32][10];
+    memset(k, 0, sizeof k);
+    for (size_t i = 0; i < t.e.size(); i++) {
+        if ((int)i >= t.n2 && (int)i < t.n2pad) continue;
+        const int col = (int)(i % 32);
+        k[col][(t.e[i].y >> 9) & 15]++;
+        if ((int)i < t.n2) { k[col][(t.e[i].y >> 25) & 15]++; k[col][9]++; }
+    }
+    for (int c = 0; c < 32; c++)
+        for (int n = 0; n < 10; n++) t.kmax = std::max(t.kmax, k[c][n]);
+    return t;
 }
 
 }  // namespace
@@ -92,8 +110,8 @@ struct sift_hip_ctx {
     uint32_t *d_desc = nullptr;
     uint32_t *d_total = nullptr;
     uint8_t *d_ori = nullptr;
-    uint32_t *d_tab = nullptr;
-    int ntab = 0;
+    uint2 *d_tab = nullptr;
+    int ntab = 0, n2 = 0, n2pad = 0;
     int blur_rows = 0;
     // profiling: a ring of `nslots` calls, one HIP event pair per kernel of a call
     struct ProfSlot { hipEvent_t ev[SIFT_HIP_NSTAGES][2] = {}; bool used[SIFT_HIP_NSTAGES] = {}; };
@@ -192,7 +210,7 @@ int run_describe(sift_hip_ctx *c, const void *d_grad, int nframes, const sift::k
     StageTimer t(c, ST_DESCRIBE, s);
     dim3 grid(c->max_kp, nframes);
     hipLaunchKernelGGL((sift::k_describe<GFMT, MODE>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out, d_desc,
-                       c->d_tab, c->ntab, c->W, c->H, c->max_kp);
+                       c->d_tab, c->n2, c->n2pad, c->ntab, c->W, c->H, c->max_kp);
     HIP_TRY(hipGetLastError());
     return SIFT_HIP_OK;
 }
@@ -242,8 +260,13 @@ int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int m
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(SIFT_HIP_ENODEV, "device is not gfx950 (the library carries gfx950 code only)");
 
-    std::vector<uint32_t> tab = build_window_table();
+    const WindowTable wt = build_window_table(width);
+    const std::vector<uint2> &tab = wt.e;
     if (tab.empty()) return fail(SIFT_HIP_EINVAL, "circle tables overlap three-fold");
+    // 16-bit bins of the describe kernel: a column's bin takes kmax pixels, and the reduction adds
+    // 4 columns before widening (describe_kernel.h)
+    if (4L * wt.kmax * sift::DESC_MAX_MAG_PACKED >= 65536)
+        return fail(SIFT_HIP_EINVAL, "descriptor window too large for 16-bit lane bins");
 
     DevGuard g(device);
     sift_hip_ctx *c = new sift_hip_ctx;
@@ -265,9 +288,9 @@ int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int m
     A((void **)&c->d_desc, B * (size_t)max_keypoints * 72 * 4);
     A((void **)&c->d_total, B * 4);
     A((void **)&c->d_ori, B * (size_t)max_keypoints);
-    A((void **)&c->d_tab, tab.size() * 4);
-    c->ntab = (int)tab.size();
-    if (e == hipSuccess) e = hipMemcpy(c->d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
+    A((void **)&c->d_tab, tab.size() * sizeof(uint2));
+    c->ntab = (int)tab.size(); c->n2 = wt.n2; c->n2pad = wt.n2pad;
+    if (e == hipSuccess) e = hipMemcpy(c->d_tab, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         sift_hip_destroy(c);
         return fail(SIFT_HIP_EHIP, "sift_hip_create", e);
