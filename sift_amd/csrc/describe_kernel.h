@@ -34,6 +34,20 @@
 // The column sums are formed with 16-byte LDS reads (lane -> row i*8 + lane/8,
 // columns 4*(lane%8)..+3) and an 8-lane DPP reduction.
 //
+// Fast path of the internal format ("quad sweep").  Gathering single 2-byte
+// pixels keeps the texture addresser busy for the whole kernel (measured:
+// TA_BUSY = 100 %, ~30 cache accesses per gather).  Keypoints whose window lies
+// inside the plane therefore read the window as aligned 8-byte quads (4 pixels
+// per lane, consecutive lanes = consecutive quads of a window row), from a
+// second table with one variant per alignment phase (px-35) & 3:
+//   lo = byte offset of the quad from the aligned window base | notov bits << 24
+//   hi = 4 x (c1 | c2 << 4), one byte per pixel of the quad
+// with circle id 9 = the overlap bins and 10, 11 = "not in the union" / "not an
+// overlap pixel" (eight spare LDS rows that are never read), so every pixel of a quad is added without a
+// test.  Quads with a two-circle pixel come first (3 adds per pixel), then the
+// rest (1 add per pixel); both lists are padded to multiples of 64 with quads
+// that only feed the spare rows.
+//
 // The gradient plane is addressed linearly like the reference does
 // (pGrad[y*WIDTH + x - 35 + col], :64/:204); indices outside the plane read
 // {0,0} (the reference would read out of bounds).  Keypoints whose window lies
@@ -71,12 +85,14 @@ template <int GFMT, int MODE>
 __global__ __launch_bounds__(64) void k_describe(const void *__restrict__ gradv, const kp_t *__restrict__ kps,
                                                  const uint8_t *__restrict__ ori_in, uint8_t *__restrict__ ori_out,
                                                  uint32_t *__restrict__ desc, const uint2 *__restrict__ tab,
-                                                 int n2, int n2pad, int ntab, int W, int H, int max_kp)
+                                                 int n2, int n2pad, int ntab, const uint2 *__restrict__ qtab,
+                                                 int qa, int qb, int W, int H, int max_kp)
 {
     constexpr bool PACK = GFMT == GRAD_PACKED16;
-    constexpr int ROWS = PACK ? 40 : 80;
+    constexpr int ROWS = PACK ? 40 : 80;         // rows that hold bins
+    constexpr int LROWS = PACK ? 48 : 80;        // + circle id 10: spare rows of the quad sweep (never read)
     constexpr int U = DESC_UNROLL;
-    __shared__ __align__(16) uint32_t hist[ROWS][32];
+    __shared__ __align__(16) uint32_t hist[LROWS][32];
     __shared__ uint32_t fin[80];
 
     const int lane = threadIdx.x;
@@ -97,7 +113,7 @@ __global__ __launch_bounds__(64) void k_describe(const void *__restrict__ gradv,
     {
         uint4 *z = reinterpret_cast<uint4 *>(&hist[0][0]);
 #pragma unroll
-        for (int i = 0; i < ROWS * 32 / 4 / 64; i++) z[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < LROWS * 32 / 4 / 64; i++) z[i * 64 + lane] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
 
@@ -108,15 +124,23 @@ __global__ __launch_bounds__(64) void k_describe(const void *__restrict__ gradv,
     const uint32_t col4 = (uint32_t)(lane & 31) * 4u;
     char *const hbase = reinterpret_cast<char *>(&hist[0][0]);
 
+    // fast path: every window pixel lies in the plane, so a gather is base(SGPR) + 32-bit offset
+    const char *__restrict__ gwin = gplane + origin * (PACK ? 2 : 4);
     auto gather = [&](auto chk, uint32_t off2, bool live) -> uint32_t {
-        long idx = origin + (long)(off2 >> 1);
-        bool ok = live;
-        if constexpr (decltype(chk)::value) ok = ok && idx >= 0 && idx < npix;
-        idx = ok ? idx : (decltype(chk)::value ? 0 : origin);
-        uint32_t g;
-        if constexpr (PACK) g = *reinterpret_cast<const uint16_t *>(gplane + idx * 2);
-        else g = *reinterpret_cast<const uint32_t *>(gplane + idx * 4);
-        return ok ? g : 0u;
+        if constexpr (decltype(chk)::value) {
+            long idx = origin + (long)(off2 >> 1);
+            const bool ok = live && idx >= 0 && idx < npix;
+            idx = ok ? idx : 0;
+            uint32_t g;
+            if constexpr (PACK) g = *reinterpret_cast<const uint16_t *>(gplane + idx * 2);
+            else g = *reinterpret_cast<const uint32_t *>(gplane + idx * 4);
+            return ok ? g : 0u;
+        } else {
+            uint32_t g;
+            if constexpr (PACK) g = *reinterpret_cast<const uint16_t *>(gwin + off2);
+            else g = *reinterpret_cast<const uint32_t *>(gwin + (off2 << 1));
+            return live ? g : 0u;
+        }
     };
     auto add = [&](uint32_t byteofs, uint32_t v) {
         atomicAdd(reinterpret_cast<uint32_t *>(hbase + byteofs), v);
@@ -125,10 +149,10 @@ __global__ __launch_bounds__(64) void k_describe(const void *__restrict__ gradv,
         if constexpr (PACK) {
             // g = mag | a << 9 (0 for code 0): value into half a&1 of row circle*4 + (a>>1)
             const uint32_t v = (g & 0x1ffu) << ((g >> 5) & 16u);
-            const uint32_t rl = ((g >> 3) & 0x180u) | col4;            // (a>>1) * 128 + column
-            add(((hi & 0x1e00u)) + rl, v);                             // circle * 512
+            const uint32_t rl = ((g >> 10) << 7) | col4;               // (a>>1) * 128 + column
+            add((hi & 0x1e00u) | rl, v);                               // circle * 512
             if constexpr (decltype(two)::value) {
-                add(((hi >> 16) & 0x1e00u) + rl, v);
+                add(((hi >> 16) & 0x1e00u) | rl, v);
                 add(36u * 128u + rl, v);
             }
         } else {
@@ -142,33 +166,80 @@ __global__ __launch_bounds__(64) void k_describe(const void *__restrict__ gradv,
             }
         }
     };
-    // entries [begin, end): lane takes begin + lane, + 64, ...; U in flight
-    auto part = [&](auto chk, auto two, int begin, int end) {
-        for (int t0 = begin; t0 < end; t0 += 64 * U) {
-            uint2 e[U];
-            uint32_t g[U];
-            bool live[U];
+    // entries [begin, end): lane takes begin + lane, + 64, ...; U in flight.  Whole chunks run
+    // without per-entry guards, the last partial chunk with them.
+    const char *__restrict__ tabc = reinterpret_cast<const char *>(tab);
+    auto chunk = [&](auto chk, auto two, auto guard, int t0, int end) {
+        uint2 e[U];
+        uint32_t g[U];
+        bool live[U];
+        const uint32_t tb = (uint32_t)(t0 + lane) * 8u;
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int t = t0 + u * 64 + lane;
-                live[u] = t < end;
-                e[u] = tab[live[u] ? t : begin];
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) g[u] = gather(chk, e[u].x, live[u]);
-#pragma unroll
-            for (int u = 0; u < U; u++) accumulate(two, e[u].y, g[u]);
+        for (int u = 0; u < U; u++) {
+            live[u] = decltype(guard)::value ? (t0 + u * 64 + lane < end) : true;
+            e[u] = *reinterpret_cast<const uint2 *>(tabc + (live[u] ? tb + (uint32_t)u * 512u : tb));
         }
+#pragma unroll
+        for (int u = 0; u < U; u++) g[u] = gather(chk, e[u].x, live[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++) accumulate(two, e[u].y, g[u]);
+    };
+    auto part = [&](auto chk, auto two, int begin, int end) {
+        int t0 = begin;
+        for (; t0 + 64 * U <= end; t0 += 64 * U) chunk(chk, two, std::false_type{}, t0, end);
+        for (; t0 < end; t0 += 64 * U) chunk(chk, two, std::true_type{}, t0, end);
     };
     auto sweep = [&](auto chk) {
         part(chk, std::true_type{}, 0, n2);
         part(chk, std::false_type{}, n2pad, ntab);
     };
+    // quad sweep (internal format, window inside the plane)
+    auto quad_pixel = [&](auto two, uint32_t g, uint32_t cc, uint32_t ovsel) {
+        // g = mag | a << 9; cc = c1 | c2 << 4 in its low byte; ovsel bit 10 set = not an overlap
+        // pixel: circle id 9 | 2 = 11, a spare row like id 10
+        const uint32_t v = (g & 0x1ffu) << ((g >> 5) & 16u);
+        const uint32_t rl = ((g >> 10) << 7) | col4;
+        add(((cc & 15u) << 9) | rl, v);
+        if constexpr (decltype(two)::value) {
+            add((((cc >> 4) & 15u) << 9) | rl, v);
+            add((ovsel & 0x400u) | (rl | (9u << 9)), v);
+        }
+    };
+    auto quad_chunk = [&](auto two, auto nu, const char *gq, const char *tq, int t0) {
+        constexpr int N = decltype(nu)::value;
+        uint2 e[N], q[N];
+        const uint32_t tb = (uint32_t)(t0 + lane) * 8u;
+#pragma unroll
+        for (int u = 0; u < N; u++) e[u] = *reinterpret_cast<const uint2 *>(tq + tb + (uint32_t)u * 512u);
+#pragma unroll
+        for (int u = 0; u < N; u++) q[u] = *reinterpret_cast<const uint2 *>(gq + (e[u].x & 0xffffffu));
+#pragma unroll
+        for (int u = 0; u < N; u++) {
+            quad_pixel(two, q[u].x & 0xffffu, e[u].y, e[u].x >> 14);
+            quad_pixel(two, q[u].x >> 16, e[u].y >> 8, e[u].x >> 15);
+            quad_pixel(two, q[u].y & 0xffffu, e[u].y >> 16, e[u].x >> 16);
+            quad_pixel(two, q[u].y >> 16, e[u].y >> 24, e[u].x >> 17);
+        }
+    };
+    auto quad_part = [&](auto two, const char *gq, const char *tq, int begin, int end) {
+        int t0 = begin;
+        for (; t0 + 64 * U <= end; t0 += 64 * U) quad_chunk(two, std::integral_constant<int, U>{}, gq, tq, t0);
+        for (; t0 < end; t0 += 64) quad_chunk(two, std::integral_constant<int, 1>{}, gq, tq, t0);
+    };
+
     // the window is rows py-35..py+35 at columns px-35..px+35 of a linearly addressed plane
-    if (origin >= 0 && origin + 70L * W + 70 < npix)
+    const bool inside = origin >= 0 && origin + 70L * W + 70 < npix;
+    if (PACK && inside && origin + 70L * W + 76 <= npix) {
+        const int phase = (px - 35) & 3;             // = origin & 3 because W % 4 == 0
+        const char *gq = gplane + (origin - phase) * 2;
+        const char *tq = reinterpret_cast<const char *>(qtab + (size_t)phase * (size_t)(qa + qb));
+        quad_part(std::true_type{}, gq, tq, 0, qa);
+        quad_part(std::false_type{}, gq, tq, qa, qa + qb);
+    } else if (inside) {
         sweep(std::false_type{});
-    else
+    } else {
         sweep(std::true_type{});
+    }
     __syncthreads();
 
     // column sums -> fin[bin], bin = circle*8 + a (72..79: overlap)
@@ -179,11 +250,11 @@ __global__ __launch_bounds__(64) void k_describe(const void *__restrict__ gradv,
             const int row = i * 8 + rsub;
             const uint4 q = *reinterpret_cast<const uint4 *>(&hist[row][cg * 4]);
             if constexpr (PACK) {
-                // 16-bit halves: 4 columns x K pixels x 360 stays below 2^16 (K = pixels of one circle
-                // that fall to one column, 27 for the reference's tables; checked on the host);
-                // widen after that
-                const uint32_t p = pk_add(pk_add(q.x, q.y), pk_add(q.z, q.w));
-                uint32_t lo = p & 0xffffu, hi = p >> 16;
+                // 16-bit halves: 2 columns x K pixels x 360 stays below 2^16 (K = pixels of one circle
+                // that fall to one column: 27 for the pixel table, 47 for the quad table of the
+                // reference's masks; checked on the host); widen after that
+                const uint32_t p01 = pk_add(q.x, q.y), p23 = pk_add(q.z, q.w);
+                uint32_t lo = (p01 & 0xffffu) + (p23 & 0xffffu), hi = (p01 >> 16) + (p23 >> 16);
                 lo += dpp_mov<0x111>(lo); hi += dpp_mov<0x111>(hi);    // row_shr:1
                 lo += dpp_mov<0x112>(lo); hi += dpp_mov<0x112>(hi);    // row_shr:2
                 lo += dpp_mov<0x114>(lo); hi += dpp_mov<0x114>(hi);    // row_shr:4

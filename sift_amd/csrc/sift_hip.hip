@@ -92,6 +92,70 @@ WindowTable build_window_table(int W)
     return t;
 }
 
+// Quad table of the describe kernel's fast path (describe_kernel.h): for each alignment
+// phase, the aligned 4-pixel quads of the 71-row window that hold a union pixel; quads with a
+// two-circle pixel first (qa entries after padding), then the rest (qb).
+struct QuadTable { std::vector<uint2> e; int qa = 0, qb = 0, kmax = 0; };
+QuadTable build_quad_table(int W)
+{
+    int c1[71][71], c2[71][71];
+    for (int y = 0; y < 71; y++)
+        for (int x = 0; x < 71; x++) c1[y][x] = c2[y][x] = 10;     // 10 = not in the union
+    for (int n = 0; n < 9; n++)
+        for (int i = 0; i < 25; i++)
+            for (int j = SIFT_CIRCLE_LO[i]; j < SIFT_CIRCLE_HI[i]; j++) {
+                int y = SIFT_YSTART[n] + i, x = SIFT_XSTART[n] + j;
+                if (c1[y][x] == 10) c1[y][x] = n; else c2[y][x] = n;
+            }
+    std::vector<uint2> A[4], B[4];
+    size_t na = 0, nb = 0;
+    for (int ph = 0; ph < 4; ph++) {
+        for (int y = 0; y < 71; y++)
+            for (int q = 0; q < 19; q++) {
+                uint32_t lo = (uint32_t)(y * W * 2 + q * 8), hi = 0;
+                bool any = false, two = false;
+                for (int p = 0; p < 4; p++) {
+                    const int x = q * 4 + p - ph;                  // window column of this pixel
+                    int a = 10, b = 10;
+                    if (x >= 0 && x < 71) { a = c1[y][x]; b = c2[y][x]; }
+                    any |= a != 10;
+                    two |= b != 10;
+                    hi |= (uint32_t)(a | b << 4) << (8 * p);
+                    if (b == 10) lo |= 1u << (24 + p);             // notov: the third add goes to the spare rows
+                }
+                if (two) A[ph].push_back(make_uint2(lo, hi));
+                else if (any) B[ph].push_back(make_uint2(lo, hi));
+            }
+        na = std::max(na, A[ph].size());
+        nb = std::max(nb, B[ph].size());
+    }
+    QuadTable t;
+    t.qa = (int)((na + 63) / 64 * 64);
+    t.qb = (int)((nb + 63) / 64 * 64);
+    const uint2 nop = make_uint2(0xfu << 24, 0xaaaaaaaau);          // offset 0, every pixel -> spare rows
+    for (int ph = 0; ph < 4; ph++) {
+        A[ph].resize((size_t)t.qa, nop);
+        B[ph].resize((size_t)t.qb, nop);
+        // pixels per (LDS column, circle | overlap) of this phase; entry i falls to column i % 32
+        int k[32][10];
+        memset(k, 0, sizeof k);
+        for (int part = 0; part < 2; part++) {
+            const std::vector<uint2> &L = part ? B[ph] : A[ph];
+            for (size_t i = 0; i < L.size(); i++)
+                for (int p = 0; p < 4; p++) {
+                    const int a = (L[i].y >> (8 * p)) & 15, b = (L[i].y >> (8 * p + 4)) & 15;
+                    if (a < 9) k[i % 32][a]++;
+                    if (!part && b < 9) { k[i % 32][b]++; k[i % 32][9]++; }
+                }
+        }
+        for (int c = 0; c < 32; c++)
+            for (int n = 0; n < 10; n++) t.kmax = std::max(t.kmax, k[c][n]);
+        t.e.insert(t.e.end(), A[ph].begin(), A[ph].end());
+        t.e.insert(t.e.end(), B[ph].begin(), B[ph].end());
+    }
+    return t;
+}
+
 }  // namespace
 
 struct sift_hip_ctx {
@@ -110,8 +174,8 @@ struct sift_hip_ctx {
     uint32_t *d_desc = nullptr;
     uint32_t *d_total = nullptr;
     uint8_t *d_ori = nullptr;
-    uint2 *d_tab = nullptr;
-    int ntab = 0, n2 = 0, n2pad = 0;
+    uint2 *d_tab = nullptr, *d_qtab = nullptr;
+    int ntab = 0, n2 = 0, n2pad = 0, qa = 0, qb = 0;
     int blur_rows = 0;
     // profiling: a ring of `nslots` calls, one HIP event pair per kernel of a call
     struct ProfSlot { hipEvent_t ev[SIFT_HIP_NSTAGES][2] = {}; bool used[SIFT_HIP_NSTAGES] = {}; };
@@ -210,7 +274,7 @@ int run_describe(sift_hip_ctx *c, const void *d_grad, int nframes, const sift::k
     StageTimer t(c, ST_DESCRIBE, s);
     dim3 grid(c->max_kp, nframes);
     hipLaunchKernelGGL((sift::k_describe<GFMT, MODE>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out, d_desc,
-                       c->d_tab, c->n2, c->n2pad, c->ntab, c->W, c->H, c->max_kp);
+                       c->d_tab, c->n2, c->n2pad, c->ntab, c->d_qtab, c->qa, c->qb, c->W, c->H, c->max_kp);
     HIP_TRY(hipGetLastError());
     return SIFT_HIP_OK;
 }
@@ -263,9 +327,10 @@ int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int m
     const WindowTable wt = build_window_table(width);
     const std::vector<uint2> &tab = wt.e;
     if (tab.empty()) return fail(SIFT_HIP_EINVAL, "circle tables overlap three-fold");
+    const QuadTable qt = build_quad_table(width);
     // 16-bit bins of the describe kernel: a column's bin takes kmax pixels, and the reduction adds
-    // 4 columns before widening (describe_kernel.h)
-    if (4L * wt.kmax * sift::DESC_MAX_MAG_PACKED >= 65536)
+    // 2 columns before widening (describe_kernel.h)
+    if (2L * std::max(wt.kmax, qt.kmax) * sift::DESC_MAX_MAG_PACKED >= 65536)
         return fail(SIFT_HIP_EINVAL, "descriptor window too large for 16-bit lane bins");
 
     DevGuard g(device);
@@ -290,6 +355,9 @@ int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int m
     A((void **)&c->d_ori, B * (size_t)max_keypoints);
     A((void **)&c->d_tab, tab.size() * sizeof(uint2));
     c->ntab = (int)tab.size(); c->n2 = wt.n2; c->n2pad = wt.n2pad;
+    c->qa = qt.qa; c->qb = qt.qb;
+    A((void **)&c->d_qtab, qt.e.size() * sizeof(uint2));
+    if (e == hipSuccess) e = hipMemcpy(c->d_qtab, qt.e.data(), qt.e.size() * sizeof(uint2), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_tab, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         sift_hip_destroy(c);
@@ -305,7 +373,7 @@ void sift_hip_destroy(sift_hip_ctx *c)
     DevGuard g(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_img, c->d_pyr, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_gradp,
-                    c->d_gradfull, c->d_kps, c->d_desc, c->d_total, c->d_ori, c->d_tab};
+                    c->d_gradfull, c->d_kps, c->d_desc, c->d_total, c->d_ori, c->d_tab, c->d_qtab};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &ps : c->prof)
         for (int i = 0; i < SIFT_HIP_NSTAGES; i++)
