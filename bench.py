@@ -23,8 +23,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# v_dot4_u32_u8: 4 MAC per lane; 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz
-DOT4_PEAK_TMACS = 256 * 4 * 32 * 4 * 2.4e9 / 1e12
+# v_dot4_u32_u8: 4 MAC per lane, one wave-instruction per 4 cycles per SIMD (measured with
+# tools/ubench/valu_rate.hip: 16 lanes/clk, like every VOP3 op): 256 CU x 4 SIMD x 16 x 4 x 2.4 GHz
+DOT4_PEAK_TMACS = 256 * 4 * 16 * 4 * 2.4e9 / 1e12
 EXPECTED_KP_1080P_SEED1 = 9493              # tests/golden/synth_expected.json, SURVEY.md 8(d) cfg 3
 
 

@@ -1,0 +1,93 @@
+// sift_main.cpp -- the reference's host flow (main.cpp:37-210) on this build: read an 8-bit gray
+// frame (binary PGM, or a synthetic frame), time one sift_detect_and_compute call, sort the
+// keypoints by contrast, keep MAX_FINAL_KEYPOINTS, write keypoints and descriptors as text.
+//   sift_main <in.pgm | synth:W:H:seed> [out_prefix] [contrastTh=15]
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "../include/HW_SIFT.hpp"
+
+static uint32_t h32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+
+static bool load(const char *arg, std::vector<uint8_t> &img, int &W, int &H)
+{
+    unsigned w, h, seed;
+    if (sscanf(arg, "synth:%u:%u:%u", &w, &h, &seed) == 3) {       // SURVEY.md 8(d) generator
+        static const int S[5] = {5, 4, 3, 2, 0}, Wt[5] = {4, 3, 2, 2, 1};
+        W = (int)w; H = (int)h; img.resize((size_t)w * h);
+        for (unsigned y = 0; y < h; y++)
+            for (unsigned x = 0; x < w; x++) {
+                uint32_t acc = 0;
+                for (int i = 0; i < 5; i++)
+                    acc += Wt[i] * (h32(seed ^ h32((y >> S[i]) * 0x9E3779B1U + (x >> S[i])) ^ (S[i] * 0x85EBCA6BU)) & 0xFF);
+                img[(size_t)y * w + x] = (uint8_t)(acc / 12);
+            }
+        return true;
+    }
+    FILE *f = fopen(arg, "rb");
+    if (!f) return false;
+    char magic[3] = {0};
+    int maxv = 0;
+    bool ok = fscanf(f, "%2s %d %d %d", magic, &W, &H, &maxv) == 4 && !strcmp(magic, "P5") && maxv == 255;
+    if (ok) {
+        fgetc(f);
+        img.resize((size_t)W * H);
+        ok = fread(img.data(), 1, img.size(), f) == img.size();
+    }
+    fclose(f);
+    return ok;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: %s <in.pgm | synth:W:H:seed> [out_prefix] [contrastTh]\n", argv[0]); return 2; }
+    std::vector<uint8_t> img;
+    int W = 0, H = 0;
+    if (!load(argv[1], img, W, H)) { fprintf(stderr, "cannot read %s\n", argv[1]); return 1; }
+    const int th = argc > 3 ? atoi(argv[3]) : 15;                  // main.cpp:73
+    sift_set_frame_size(W, H);
+
+    Pixel_t *src = (Pixel_t *)sift_alloc((size_t)W * H);           // main.cpp:18-32
+    Keypoint_t *kps = (Keypoint_t *)sift_alloc(MAX_KEYPOINTS * sizeof(Keypoint_t));
+    Desc_t *desc = (Desc_t *)sift_alloc((size_t)MAX_KEYPOINTS * DESC_SIZE * sizeof(Desc_t));
+    if (!src || !kps || !desc) { fprintf(stderr, "pinned allocation failed\n"); return 1; }
+    memcpy(src, img.data(), img.size());                           // main.cpp:55-58
+
+    sift_detect_and_compute(src, kps, desc, th);                   // warm-up: creates the context
+    auto t0 = std::chrono::steady_clock::now();                    // main.cpp:63-77
+    sift_detect_and_compute(src, kps, desc, th);
+    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+
+    int n = 0;
+    while (n < MAX_KEYPOINTS && kps[n].contrast) n++;
+    printf("%dx%d: %d keypoints, %.3f ms (host buffers in, host buffers out)\n", W, H, n, ms);
+
+    // main.cpp:82-84: sort by contrast, keep the strongest MAX_FINAL_KEYPOINTS.  The reference's
+    // std::sort is unstable; ties are broken here by raster position.  Descriptors stay in raster
+    // order (main.cpp:82 does not permute them), so each sorted keypoint carries its raster index.
+    std::vector<int> order(n);
+    for (int i = 0; i < n; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) {
+        return kps[a].contrast != kps[b].contrast ? kps[a].contrast > kps[b].contrast : a < b; });
+    const int keep = std::min(n, MAX_FINAL_KEYPOINTS);
+    if (argc > 2) {
+        std::string p = argv[2];
+        FILE *f = fopen((p + "_keypoints.txt").c_str(), "w");
+        FILE *g = fopen((p + "_descriptors.txt").c_str(), "w");
+        if (!f || !g) { fprintf(stderr, "cannot write outputs\n"); return 1; }
+        for (int i = 0; i < keep; i++) {
+            const int k = order[i];
+            fprintf(f, "%d %u %u %u\n", k, (unsigned)kps[k].x, (unsigned)kps[k].y, (unsigned)kps[k].contrast);
+            for (int j = 0; j < DESC_SIZE; j++) fprintf(g, "%u%c", (unsigned)desc[(size_t)k * DESC_SIZE + j], j + 1 < DESC_SIZE ? ' ' : '\n');
+        }
+        fclose(f); fclose(g);
+    }
+    sift_free(src); sift_free(kps); sift_free(desc);
+    sift_shutdown();
+    return 0;
+}

@@ -1,0 +1,22 @@
+// HW_SIFT.hpp -- sift_detect_and_compute with the reference's signature
+// (/root/reference/src/HW_SIFT.hpp:11-15, HW_SIFT.cpp:16-50), served by the MI355X library
+// through the C ABI of sift_hip.h.  Link with -lhw_sift -lsift_hip.
+#pragma once
+#include "SIFTParameters.hpp"
+
+// frame -> MAX_KEYPOINTS keypoints (zero padded) + MAX_KEYPOINTS x DESC_SIZE descriptor words.
+// Like the reference it returns nothing; a failure of the device path prints the library's error
+// text and aborts (the reference has no error channel).
+void sift_detect_and_compute(Pixel_t *pSrcImageCam0, Keypoint_t *pKeypoints, Desc_t *pDesc, int contrastTh);
+
+// ---- additions of this build (no counterpart in the reference) ---------------------------------
+// Frame size used by the four entry points; defaults to WIDTH x HEIGHT.  Must be called while no
+// other thread is inside an entry point; it drops the cached device context.
+void sift_set_frame_size(int width, int height);
+// HIP device the entry points run on (default 0).
+void sift_set_device(int device);
+// Releases the cached device context (optional; done at process exit otherwise).
+void sift_shutdown(void);
+// Pinned host buffers, the counterpart of sds_alloc / sds_free (main.cpp:18-32, :214-217).
+void *sift_alloc(unsigned long bytes);
+void sift_free(void *p);

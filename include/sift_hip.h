@@ -72,6 +72,11 @@ const char *sift_hip_last_error(void);
 /* Number of HIP devices visible (0 if none / runtime unusable). */
 int sift_hip_device_count(void);
 
+/* Pinned host memory for image / keypoint / descriptor buffers: the counterpart of
+ * sds_alloc and sds_free (main.cpp:18-32, :214-217).  NULL on failure. */
+void *sift_hip_host_alloc(unsigned long bytes);
+void sift_hip_host_free(void *p);
+
 /* ---- host-buffer entry points (the reference's four hardware functions) -- */
 
 /* sift_detect_and_compute, HW_SIFT.hpp:11-15 / HW_SIFT.cpp:16-50.

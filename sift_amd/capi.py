@@ -23,6 +23,7 @@ GRAD_DTYPE = np.dtype([("ang", "<u2"), ("mag", "<u2")])
 # every symbol include/sift_hip.h declares (tests check the library exports all)
 EXPORTS = (
     "sift_hip_create", "sift_hip_destroy", "sift_hip_last_error", "sift_hip_device_count",
+    "sift_hip_host_alloc", "sift_hip_host_free",
     "sift_hip_detect_and_compute", "sift_hip_detect", "sift_hip_main_orientation", "sift_hip_descriptor",
     "sift_hip_batch", "sift_hip_detect_and_compute_dev", "sift_hip_detect_dev",
     "sift_hip_main_orientation_dev", "sift_hip_descriptor_dev", "sift_hip_sync", "sift_hip_debug_planes",
@@ -46,6 +47,7 @@ def build_library(force=False):
     if force:
         subprocess.check_call(["make", "-s", "-C", src, "clean"])
     subprocess.check_call(["make", "-s", "-C", src])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "host")])
     return _LIB
 
 
@@ -63,6 +65,10 @@ def load_library():
     lib.sift_hip_last_error.restype = C.c_char_p
     lib.sift_hip_stage_name.restype = C.c_char_p
     lib.sift_hip_stage_name.argtypes = [i32]
+    lib.sift_hip_host_alloc.restype = vp
+    lib.sift_hip_host_alloc.argtypes = [C.c_ulong]
+    lib.sift_hip_host_free.restype = None
+    lib.sift_hip_host_free.argtypes = [vp]
     lib.sift_hip_destroy.restype = None
     lib.sift_hip_destroy.argtypes = [vp]
     lib.sift_hip_create.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32]

@@ -189,8 +189,8 @@ namespace {
 
 struct DevGuard {
     int prev = -1;
-    explicit DevGuard(int dev) { hipGetDevice(&prev); if (prev != dev) hipSetDevice(dev); else prev = -1; }
-    ~DevGuard() { if (prev >= 0) hipSetDevice(prev); }
+    explicit DevGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
 struct StageTimer {
@@ -302,6 +302,20 @@ int sift_hip_device_count(void)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+void *sift_hip_host_alloc(unsigned long bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0) bytes = 1;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { fail(SIFT_HIP_EHIP, "hipHostMalloc", e); return nullptr; }
+    return p;
+}
+
+void sift_hip_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 const char *sift_hip_stage_name(int stage)
