@@ -21,14 +21,18 @@
 //     floor(S + 0.5); the clamp to 255 (:848-851) can never fire because
 //     255 * sum(Kq) + 16384 < 256 * 32768 for all three tables (static_assert).
 //
-// Output: one interleaved word per pixel  src | G1<<8 | G2<<16 | G3<<24
-// ("pyr" plane) -- 16-byte stores per lane, and the detect kernel gets every
-// plane of a neighbour with a single load.  G1/G2 rows finish 7/4 input rows
-// before the G3 row of the same image row; they wait in packed delay lines.
+// Output ("pyr" plane): one uint4 per group of 4 pixels = { src, G1, G2, G3 },
+// each a dword with pixel p of the group in byte p -- a 16-byte store per lane
+// with no byte shuffling, and the detect kernel (4 pixels per lane as well)
+// gets all four planes of its pixels with one load.  G1/G2 rows finish 7/4
+// input rows before the G3 row of the same image row; they wait in packed
+// delay lines.
 //
 // No LDS, no barriers: neighbouring threads' loads overlap and are served by
-// the vector L1.  Out-of-image taps read 0 (DetectKeypoints.cpp:968-991; the
-// top rows, uninitialised in the reference, are defined as 0).
+// the vector L1; the next input row is loaded one iteration ahead.  Out-of-image
+// taps read 0 (DetectKeypoints.cpp:968-991; the top rows, uninitialised in the
+// reference, are defined as 0): rows outside the image are read from a row of
+// zeros, columns outside are masked.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -92,41 +96,52 @@ static_assert(ksum<1>() == 32765 && ksum<2>() == 32759 && ksum<3>() == 32744, "t
 static_assert(255 * ksum<1>() + 16384 < 256 * 32768L, "clamp cannot fire");
 static_assert(kdw<3>(9, 2, 1) != 0 && kdw<3>(0, 0, 1) == 0, "hi plane only near the centre");
 
-// acc + sum_j W_j . K[R][j]   (lo plane into acc, hi plane into a temp, folded <<8)
-template <int WHICH, int R>
-__device__ __forceinline__ uint32_t row_mac(const uint32_t (&w)[5], uint32_t acc)
-{
-    static_for<0, 5>([&](auto jj) {
-        constexpr int j = jj;
-        constexpr uint32_t k = kdw<WHICH>(R, j, 0);
-        if constexpr (k != 0) acc = __builtin_amdgcn_udot4(w[j], k, acc, false);
-    });
-    constexpr bool any_hi = (kdw<WHICH>(R, 0, 1) | kdw<WHICH>(R, 1, 1) | kdw<WHICH>(R, 2, 1) |
-                             kdw<WHICH>(R, 3, 1) | kdw<WHICH>(R, 4, 1)) != 0;
-    if constexpr (any_hi) {
-        uint32_t h = 0;
-        static_for<0, 5>([&](auto jj) {
-            constexpr int j = jj;
-            constexpr uint32_t k = kdw<WHICH>(R, j, 1);
-            if constexpr (k != 0) h = __builtin_amdgcn_udot4(w[j], k, h, false);
-        });
-        acc = (h << 8) + acc;
-    }
-    return acc;
-}
-
 constexpr uint32_t BLUR_INIT = 16384u;   // the +0.5 of RoundToInt in Q15
 
-// One input row into the slots [LO,HI) of table WHICH (N = table size).
+template <int WHICH, int R>
+constexpr bool row_has_hi()
+{
+    return (kdw<WHICH>(R, 0, 1) | kdw<WHICH>(R, 1, 1) | kdw<WHICH>(R, 2, 1) | kdw<WHICH>(R, 3, 1) |
+            kdw<WHICH>(R, 4, 1)) != 0;
+}
+
+// One input row into the slots [LO,HI) of table WHICH (N = table size): slot s takes table row
+// N-1-s and the old slot s+1 as its addend (ascending s, so the old value is still there).
+// The four pixels of the thread are interleaved instruction by instruction: a v_dot4 that feeds
+// the next one's accumulator back to back costs a wait state (the compiler pads with s_nop).
 template <int WHICH, int LO, int HI>
 __device__ __forceinline__ void slide(uint32_t (&a)[ksize<WHICH>()][4], const uint32_t (&w)[4][5])
 {
     constexpr int N = ksize<WHICH>();
     static_for<LO, HI>([&](auto ss) {
         constexpr int s = ss;
+        constexpr int R = N - 1 - s;
+        uint32_t acc[4];
 #pragma unroll
-        for (int p = 0; p < 4; p++)
-            a[s][p] = row_mac<WHICH, N - 1 - s>(w[p], s == N - 1 ? BLUR_INIT : a[s + 1 < N ? s + 1 : s][p]);
+        for (int p = 0; p < 4; p++) acc[p] = (s == N - 1) ? BLUR_INIT : a[s + 1 < N ? s + 1 : s][p];
+        static_for<0, 5>([&](auto jj) {
+            constexpr int j = jj;
+            constexpr uint32_t k = kdw<WHICH>(R, j, 0);
+            if constexpr (k != 0) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) acc[p] = __builtin_amdgcn_udot4(w[p][j], k, acc[p], false);
+            }
+        });
+        if constexpr (row_has_hi<WHICH, R>()) {
+            uint32_t h[4] = {0, 0, 0, 0};
+            static_for<0, 5>([&](auto jj) {
+                constexpr int j = jj;
+                constexpr uint32_t k = kdw<WHICH>(R, j, 1);
+                if constexpr (k != 0) {
+#pragma unroll
+                    for (int p = 0; p < 4; p++) h[p] = __builtin_amdgcn_udot4(w[p][j], k, h[p], false);
+                }
+            });
+#pragma unroll
+            for (int p = 0; p < 4; p++) acc[p] = (h[p] << 8) + acc[p];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) a[s][p] = acc[p];
     });
 }
 
@@ -138,10 +153,14 @@ __device__ __forceinline__ uint32_t pack4_q15(const uint32_t (&a)[4])
     return lo | (hi << 16);
 }
 
-// grid: x = ceil(W/4 / 256) blocks of 256 threads, y = strips, z = frames
+// "pyr" plane: one uint4 per group of 4 pixels = { src, G1, G2, G3 }, each a dword with pixel p
+// of the group in byte p.
+//
+// grid: x = ceil(W/4 / blockDim) blocks, y = strips, z = frames.  `zero_row` points at >= W bytes
+// of zeros: rows outside the image are read from there, so the row loads need no test.
 template <bool GUARD>
-__global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, uint32_t *__restrict__ pyr,
-                                              int W, int H, int rows)
+__global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, uint4 *__restrict__ pyr,
+                                              const uint32_t *__restrict__ zero_row, int W, int H, int rows)
 {
     const int W4 = W >> 2;
     const int xq = blockIdx.x * blockDim.x + threadIdx.x;
@@ -150,25 +169,24 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, 
     const int ye = min(H, ys + rows);
     const size_t fofs = (size_t)blockIdx.z * (size_t)W * (size_t)H;
     const uint32_t *__restrict__ img = reinterpret_cast<const uint32_t *>(imgs + fofs);
-    uint32_t *__restrict__ out = pyr + fofs;
+    uint4 *__restrict__ out = pyr + (fofs >> 2);
 
-    // column part of the 7 raw-dword addresses and their validity
-    int qc[7];
-    bool cv[7];
+    // column part of the 7 raw-dword addresses; columns outside the row are masked to 0
+    uint32_t qc[7], cm[7];
 #pragma unroll
     for (int k = 0; k < 7; k++) {
-        int q = xq - 3 + k;
-        cv[k] = (q >= 0) && (q < W4);
-        qc[k] = cv[k] ? q : xq;
+        const int q = xq - 3 + k;
+        const bool v = (q >= 0) && (q < W4);
+        cm[k] = v ? 0xffffffffu : 0u;
+        qc[k] = (uint32_t)(v ? q : xq) * 4u;
     }
+    auto row_ptr = [&](int i) -> const char * {      // wave-uniform
+        return reinterpret_cast<const char *>((i >= 0 && i < H) ? img + (size_t)i * W4 : zero_row);
+    };
     auto load_row = [&](int i, uint32_t (&A)[7]) {
-        const bool rv = (i >= 0) && (i < H);
-        const uint32_t *rp = img + (size_t)(rv ? i : 0) * W4;
+        const char *rp = row_ptr(i);
 #pragma unroll
-        for (int k = 0; k < 7; k++) {
-            uint32_t v = rp[qc[k]];
-            A[k] = (rv && cv[k]) ? v : 0u;
-        }
+        for (int k = 0; k < 7; k++) A[k] = *reinterpret_cast<const uint32_t *>(rp + qc[k]);
     };
 
     uint32_t a3[19][4], a2[11][4], a1[5][4];
@@ -189,16 +207,22 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, 
     uint32_t cur[7], nxt[7];
     load_row(ys - 9, cur);
     for (int i = ys - 9; i < ye + 9; ++i) {
-        load_row(i + 1, nxt);                 // prefetch; a row past the strip is harmless (clamped / zero)
+        load_row(i + 1, nxt);                 // prefetch: consumed in the next iteration
+        // source dword of the row that finishes in this iteration (used at the bottom)
+        const int y3 = i - 9;
+        const uint32_t sp = *reinterpret_cast<const uint32_t *>(row_ptr(y3) + qc[3]);
 
         // window dwords: pixel p's window starts at byte 3+p of cur[]
+        uint32_t c[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) c[k] = cur[k] & cm[k];
         uint32_t w[4][5];
 #pragma unroll
         for (int j = 0; j < 5; j++) {
-            w[0][j] = __builtin_amdgcn_alignbyte(cur[j + 1], cur[j], 3);
-            w[1][j] = cur[j + 1];
-            w[2][j] = __builtin_amdgcn_alignbyte(cur[j + 2], cur[j + 1], 1);
-            w[3][j] = __builtin_amdgcn_alignbyte(cur[j + 2], cur[j + 1], 2);
+            w[0][j] = __builtin_amdgcn_alignbyte(c[j + 1], c[j], 3);
+            w[1][j] = c[j + 1];
+            w[2][j] = __builtin_amdgcn_alignbyte(c[j + 2], c[j + 1], 1);
+            w[3][j] = __builtin_amdgcn_alignbyte(c[j + 2], c[j + 1], 2);
         }
 
         if constexpr (GUARD) {
@@ -221,16 +245,13 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, 
         }
 
         // finished rows: G1 row i-2, G2 row i-5, G3 row i-9
-        const int y3 = i - 9;
         if (y3 >= ys) {                       // y3 < ye holds by the loop bound
-            const uint32_t g1 = d1[6], g2 = d2[3];
-            const uint32_t sp = img[(size_t)y3 * W4 + xq];
             uint4 o;
-            o.x = (sp & 0xffu) | ((g1 & 0xffu) << 8) | ((g2 & 0xffu) << 16) | ((a3[0][0] >> 15) << 24);
-            o.y = ((sp >> 8) & 0xffu) | (((g1 >> 8) & 0xffu) << 8) | (((g2 >> 8) & 0xffu) << 16) | ((a3[0][1] >> 15) << 24);
-            o.z = ((sp >> 16) & 0xffu) | (((g1 >> 16) & 0xffu) << 8) | (((g2 >> 16) & 0xffu) << 16) | ((a3[0][2] >> 15) << 24);
-            o.w = (sp >> 24) | ((g1 >> 24) << 8) | ((g2 >> 24) << 16) | ((a3[0][3] >> 15) << 24);
-            *reinterpret_cast<uint4 *>(out + (size_t)y3 * W + 4 * (size_t)xq) = o;
+            o.x = sp;
+            o.y = d1[6];
+            o.z = d2[3];
+            o.w = pack4_q15(a3[0]);
+            out[(size_t)y3 * W4 + xq] = o;
         }
 #pragma unroll
         for (int k = 6; k > 0; k--) d1[k] = d1[k - 1];

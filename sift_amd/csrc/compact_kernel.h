@@ -1,21 +1,19 @@
-// compact_kernel.h -- 7x7 cull on the sparse candidate set, border filter and
+// compact_kernel.h -- edge test and 7x7 cull on the sparse candidate list, border filter and
 // raster-ordered compaction into Keypoint_t[max_kp].
 //
-// Restates culling_hls + IsBestKeypoint (DetectKeypoints.cpp:567-750) and
-// combine_keypoints_hls (:372-439).  Candidates are ~0.5 % of the pixels, so
-// the cull works on the ballot masks of k_detect instead of on dense planes:
-// a lane owns one 64-pixel segment, finds the candidates in the 7x7 window of
-// each of its candidates by shifting the neighbouring masks, and only then
-// reads their keys.  The compaction is rank based (per-row counts, then an
-// in-row wave scan), which reproduces the reference's raster order and its
-// "first max_kp in raster order" cap without a sort.
+// Restates IsOnEdge (DetectKeypoints.cpp:314-352), culling_hls + IsBestKeypoint (:567-750) and
+// combine_keypoints_hls (:372-439).  The pixels that pass the extremum and contrast tests are
+// ~1 % of the frame, so everything after k_detect works on its list and bit masks instead of on
+// dense planes.  The compaction is rank based (per-row counts, then an in-row wave scan), which
+// reproduces the reference's raster order and its "first max_kp in raster order" cap without a
+// sort.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "detect_kernel.h"
 
 namespace sift {
 
-typedef unsigned long long u64;
 
 struct kp_t { uint16_t x, y; uint32_t contrast; };   // Keypoint_t, SIFTParameters.hpp:79-85
 
@@ -46,49 +44,94 @@ __device__ __forceinline__ u64 border_mask(int y, int seg, int W, int H)
     return m;
 }
 
-// One wave per image row, lane = segment.  grid: x = ceil(H/4) blocks of 256, y = frames.
-__global__ __launch_bounds__(256) void k_cull(const u64 *__restrict__ candmask,
-                                              const uint32_t *__restrict__ keyplane,
-                                              u64 *__restrict__ survmask, uint32_t *__restrict__ rowcount,
-                                              int W, int H, int S)
+// D2 = G2 - G1 at (y, x) from the planar pyr plane, 0 outside the image
+__device__ __forceinline__ int pyr_d2_at(const uint4 *__restrict__ fp, int W4, int W, int H, int y, int x)
 {
-    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (y >= H) return;
-    const int lane = threadIdx.x & 63;
-    const size_t frow = (size_t)blockIdx.y * H;
-    const u64 *__restrict__ cm = candmask + frow * S;
-    const uint32_t *__restrict__ kp = keyplane + (size_t)blockIdx.y * (size_t)W * (size_t)H;
-    uint32_t cnt = 0;
-    for (int seg = lane; seg < S; seg += 64) {
-        const u64 m = cm[(size_t)y * S + seg];
-        u64 keep = m;
-        u64 it = m;
-        while (it) {
-            const int b = __ffsll((long long)it) - 1;
-            it &= it - 1;
-            const int x = seg * 64 + b;
-            const uint32_t ec = kp[(size_t)y * W + x] >> 8;
-            bool best = true;
-            for (int dy = -3; dy <= 3 && best; dy++) {
-                const int yy = y + dy;
-                if (yy < 0 || yy >= H) continue;
-                uint32_t f = mask_field7(cm + (size_t)yy * S, S, x - 3);
-                if (dy == 0) f &= ~8u;               // not the keypoint itself (:728)
-                while (f) {
-                    const int k = __ffs((int)f) - 1;
-                    f &= f - 1;
-                    const uint32_t en = kp[(size_t)yy * W + (x - 3 + k)] >> 8;
-                    if (!(ec < en)) { best = false; break; }   // strict (:730)
-                }
+    if (y < 0 || y >= H || x < 0 || x >= W) return 0;
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(fp + (size_t)y * W4 + (x >> 2));
+    const int sh = (x & 3) * 8;
+    return (int)((q[2] >> sh) & 0xffu) - (int)((q[1] >> sh) & 0xffu);
+}
+
+// IsOnEdge (:314-352) + float -> ap_fixed<32,17,AP_RND_ZERO>: Q15 ratio or -1.
+__device__ __forceinline__ int edge_ratio_q15(int L, int R, int U, int Dn, int UL, int UR, int DL, int DR, int c)
+{
+    const int fxx = L + R - 2 * c;
+    const int fyy = U + Dn - 2 * c;
+    const int fxy = UL + DR - DL - UR;
+    const int tr = fxx + fyy;
+    const int det = fxx * fyy - fxy * fxy;
+    if (det == 0) return -1;
+    // both operands are exact in binary32 (|.| < 2^24); __fdiv_rn is the IEEE
+    // correctly rounded divide whatever the fast-math flags are
+    const float r = __fdiv_rn((float)(tr * tr), (float)det);
+    if (r < 0.0f || r > 12.0f) return -1;            // EIGEN_RATIO_TH, DetectKeypoints.hpp:18
+    // r * 2^15 is exact in binary32 (r <= 12); round to nearest, ties toward zero
+    const float v = r * 32768.0f;
+    const float fl = floorf(v);
+    return (int)fl + ((v - fl) > 0.5f ? 1 : 0);
+}
+
+// Q15 edge ratio of the pixel (y, x), -1 if the edge test rejects it; *contrast = |D2|
+__device__ __forceinline__ int edge_at(const uint4 *__restrict__ fp, int W4, int W, int H, int y, int x, int *contrast)
+{
+    const int c = pyr_d2_at(fp, W4, W, H, y, x);
+    if (contrast) *contrast = c < 0 ? -c : c;
+    return edge_ratio_q15(pyr_d2_at(fp, W4, W, H, y, x - 1), pyr_d2_at(fp, W4, W, H, y, x + 1),
+                          pyr_d2_at(fp, W4, W, H, y - 1, x), pyr_d2_at(fp, W4, W, H, y + 1, x),
+                          pyr_d2_at(fp, W4, W, H, y - 1, x - 1), pyr_d2_at(fp, W4, W, H, y - 1, x + 1),
+                          pyr_d2_at(fp, W4, W, H, y + 1, x - 1), pyr_d2_at(fp, W4, W, H, y + 1, x + 1), c);
+}
+
+// Edge test + 7x7 cull, one lane per pixel of k_detect's list (strict extrema above the contrast
+// threshold, ~1 % of the pixels).  A listed pixel whose edge ratio is valid is a pre-cull
+// candidate (kpMap1 != 0, :190-207): its bit is set in candmask and keyplane gets
+// (E_q15 << 8) | contrast.  It survives the cull iff its ratio is strictly smaller than that of
+// every OTHER pre-cull candidate in the 7x7 window (:728-731, :684); the ratios of the listed
+// pixels in the window are recomputed here instead of being exchanged between lanes.
+// Survivors get their bit in survmask and, inside the border, count in rowcount[y].
+// grid: x = blocks of 256 (grid-stride over the list), y = frames.
+__global__ __launch_bounds__(256) void k_cand(const uint4 *__restrict__ pyr, const u64 *__restrict__ premask,
+                                              const uint32_t *__restrict__ list,
+                                              const uint32_t *__restrict__ listcount, u64 *__restrict__ candmask,
+                                              u64 *__restrict__ survmask, uint32_t *__restrict__ keyplane,
+                                              uint32_t *__restrict__ rowcount, int W, int H, int S, int list_cap)
+{
+    const int frame = blockIdx.y;
+    const int W4 = W >> 2;
+    const size_t fpix = (size_t)frame * (size_t)W * (size_t)H;
+    const uint4 *__restrict__ fp = pyr + (fpix >> 2);
+    const size_t frow = (size_t)frame * H;
+    const u64 *__restrict__ pm = premask + frow * S;
+    const uint32_t n = min(listcount[frame], (uint32_t)list_cap);
+    const uint32_t *__restrict__ fl = list + (size_t)frame * list_cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t e = fl[i];
+        const int y = (int)(e >> 16), x = (int)(e & 0xffffu);
+        int ac;
+        const int ec = edge_at(fp, W4, W, H, y, x, &ac);
+        if (ec < 0) continue;                                        // :200 -- not a candidate
+        const u64 bit = 1ull << (x & 63);
+        atomicOr(candmask + (frow + y) * S + (x >> 6), bit);
+        keyplane[fpix + (size_t)y * W + x] = ((uint32_t)ec << 8) | (uint32_t)ac;
+        bool best = true;
+        for (int dy = -3; dy <= 3 && best; dy++) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            uint32_t f = mask_field7(pm + (size_t)yy * S, S, x - 3);
+            if (dy == 0) f &= ~8u;                                   // not the keypoint itself (:728)
+            while (f) {
+                const int k = __ffs((int)f) - 1;
+                f &= f - 1;
+                const int en = edge_at(fp, W4, W, H, yy, x - 3 + k, nullptr);
+                if (en >= 0 && !(ec < en)) { best = false; break; }  // strict (:730)
             }
-            if (!best) keep &= ~(1ull << b);
         }
-        survmask[(frow + y) * S + seg] = keep;
-        cnt += (uint32_t)__popcll(keep & border_mask(y, seg, W, H));
+        if (best) {
+            atomicOr(survmask + (frow + y) * S + (x >> 6), bit);
+            if (border_mask(y, x >> 6, W, H) & bit) atomicAdd(rowcount + frow + y, 1u);
+        }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-    if (lane == 0) rowcount[frow + y] = cnt;
 }
 
 // One wave per image row (+ one extra wave per frame for padding / totals).

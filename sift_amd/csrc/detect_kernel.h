@@ -1,51 +1,35 @@
-// detect_kernel.h -- DoG, 3x3x3 extremum, contrast, edge ratio and the gradient
-// plane, from the interleaved "pyr" words written by k_blur.
+// detect_kernel.h -- DoG, 3x3x3 extremum, contrast test and the gradient plane, from the planar
+// "pyr" words written by k_blur.
 //
-// Restates build_DOG_hls (DetectKeypoints.cpp:511-559), detect_extrema_hls +
-// IsLocalExtremum + IsOnEdge (:44-223, :234-308, :314-352) and
-// ComputeGradientsHLS + ComputeGradientKernel (:1273-1363, :1186-1225).
+// Restates build_DOG_hls (DetectKeypoints.cpp:511-559), detect_extrema_hls + IsLocalExtremum
+// (:44-223, :234-308, without the edge test, which k_cand applies to the few pixels that get
+// this far) and ComputeGradientsHLS + ComputeGradientKernel (:1273-1363, :1186-1225).
 //
-// A wave owns a 64-pixel row segment and walks down `rows` image rows keeping
-// the three most recent rows of (x-1, x, x+1) words in registers, so each
-// image row costs three cached dword loads per lane and no LDS.  The DoG
-// planes are never materialised: D1 = G1-src, D2 = G2-G1, D3 = G3-G2 are byte
-// differences inside a word, and every out-of-image neighbour is the word 0,
-// which gives D = 0 and G2 = 0 exactly as the reference's zero fill does.
+// A lane owns 4 adjacent pixels (one uint4 of pyr = src, G1, G2, G3 dwords) and walks down
+// `rows` image rows; a wave covers 256 columns.  The DoG planes are never materialised:
+// D1 = G1-src, D2 = G2-G1, D3 = G3-G2 are byte differences, and every out-of-image neighbour
+// reads as 0, which gives D = 0 and G2 = 0 exactly as the reference's zero fill does.
+//
+// The 26-neighbour test is separable: per column and row keep e = max(D1,D3), f = min(D1,D3)
+// and b = D2; per column the max/min over the three rows; then a pixel's neighbourhood maximum is
+//   max( E[x-1], E[x], E[x+1], Ball[x-1], Ball[x+1], max(b[y-1][x], b[y+1][x]) ).
+// Left/right columns are in the lane for the inner pixels and come from the neighbouring lane by
+// DPP wave shifts for the outer ones; lanes 0 and 63 compute the one column beyond the wave
+// themselves (the "halo" column; the DPP shift leaves their `old` value in place).
 //
 // Outputs per frame
-//   candmask[y][seg]  u64 ballot of pre-cull candidates (kpMap1 != 0)
-//   keyplane[y][x]    u32, written ONLY at candidates: (E_q15 << 8) | |D2|
-//   gradp[y][x]       u16 mag | (ang-1) << 9, 0 for ang 0  (internal, 2 B/pixel; describe_kernel.h)
-//   gradfull[y][x]    Grad_t {ang, mag}              (optional, sift_detect API)
+//   premask[y][seg]   u64, bit = pixel is a strict extremum with |D2| >= contrastTh (raster order)
+//   list[]            the same pixels as (y << 16 | x), appended per strip (order irrelevant)
+//   gradp[y][x]       u16 mag | (code-1) << 9, 0 for code 0   (internal, 2 B/pixel)
+//   gradfull[y][x]    Grad_t {ang, mag}                        (optional, sift_detect API)
+// and it zeroes candmask / survmask / rowcount, which k_cand fills with atomics.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace sift {
 
-__device__ __forceinline__ int pyr_d1(uint32_t w) { return (int)((w >> 8) & 0xff) - (int)(w & 0xff); }
-__device__ __forceinline__ int pyr_d2(uint32_t w) { return (int)((w >> 16) & 0xff) - (int)((w >> 8) & 0xff); }
-__device__ __forceinline__ int pyr_d3(uint32_t w) { return (int)(w >> 24) - (int)((w >> 16) & 0xff); }
-__device__ __forceinline__ int pyr_g2(uint32_t w) { return (int)((w >> 16) & 0xff); }
-
-// IsOnEdge (:314-352) + float -> ap_fixed<32,17,AP_RND_ZERO>: Q15 ratio or -1.
-__device__ __forceinline__ int edge_ratio_q15(int L, int R, int U, int Dn, int UL, int UR, int DL, int DR, int c)
-{
-    const int fxx = L + R - 2 * c;
-    const int fyy = U + Dn - 2 * c;
-    const int fxy = UL + DR - DL - UR;
-    const int tr = fxx + fyy;
-    const int det = fxx * fyy - fxy * fxy;
-    if (det == 0) return -1;
-    // both operands are exact in binary32 (|.| < 2^24); __fdiv_rn is the IEEE
-    // correctly rounded divide whatever the fast-math flags are
-    const float r = __fdiv_rn((float)(tr * tr), (float)det);
-    if (r < 0.0f || r > 12.0f) return -1;            // EIGEN_RATIO_TH, DetectKeypoints.hpp:18
-    // r * 2^15 is exact in binary32 (r <= 12); round to nearest, ties toward zero
-    const float v = r * 32768.0f;
-    const float fl = floorf(v);
-    return (int)fl + ((v - fl) > 0.5f ? 1 : 0);
-}
+typedef unsigned long long u64;
 
 // internal 2-byte gradient word (written by k_detect, read by k_describe): mag | (code-1) << 9,
 // and 0 for code 0, whose magnitude never reaches a descriptor bin
@@ -54,13 +38,13 @@ __device__ __forceinline__ uint32_t gradp_pack(int ang, int mag)
     return ang ? ((uint32_t)mag | ((uint32_t)(ang - 1) << 9)) : 0u;
 }
 
-// ComputeGradientKernel (:1186-1225)
+// ComputeGradientKernel (:1186-1225).  mag = floor(sqrt(s)), s = gx^2+gy^2 <= 130050: with s exact
+// in binary32, floor(sqrt(s + 0.5)) equals the integer square root even with a 1-ulp sqrt (the
+// distance of sqrt(s + 0.5) to the nearest integer is >= 0.25/361).
 __device__ __forceinline__ void grad_code(int gx, int gy, int &ang, int &mag)
 {
-    const int s = gx * gx + gy * gy;                 // <= 130050
-    int m = (int)__fsqrt_rn((float)s);
-    m -= (m * m > s) ? 1 : 0;                        // guards: exact integer sqrt whatever
-    m += ((m + 1) * (m + 1) <= s) ? 1 : 0;           // the rounding of the float root
+    const int s = gx * gx + gy * gy;
+    mag = (int)__builtin_amdgcn_sqrtf((float)s + 0.5f);   // v_sqrt_f32
     const int ax = gx < 0 ? -gx : gx, ay = gy < 0 ? -gy : gy;
     int a = 0;
     if (gx > 0 && gy > 0) a = ax > ay ? 1 : 2;
@@ -68,83 +52,228 @@ __device__ __forceinline__ void grad_code(int gx, int gy, int &ang, int &mag)
     else if (gx < 0 && gy < 0) a = ax > ay ? 5 : 6;
     else if (gx > 0 && gy < 0) a = ax < ay ? 7 : 8;
     ang = a;
-    mag = m;
 }
 
-// grid: x = ceil(W/256), y = strips, z = frames; block 256 (4 segments)
-template <bool FULLGRAD>
-__global__ __launch_bounds__(256) void k_detect(const uint32_t *__restrict__ pyr,
-                                                unsigned long long *__restrict__ candmask,
-                                                uint32_t *__restrict__ keyplane, uint16_t *__restrict__ gradp,
-                                                uint32_t *__restrict__ gradfull, int W, int H, int S, int rows,
-                                                int contrastTh)
-{
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    const int seg = x >> 6;
-    if (seg >= S) return;                            // whole wave out (wave-uniform)
-    const int ys = blockIdx.y * rows;
-    const int ye = min(H, ys + rows);
-    const size_t fpix = (size_t)blockIdx.z * (size_t)W * (size_t)H;
-    const uint32_t *__restrict__ p = pyr + fpix;
-    const bool xin = x < W;
-    const bool lin = xin && x >= 1, rin = x + 1 < W;
-    const int xc = xin ? x : 0;
+__device__ __forceinline__ int byte_of(uint32_t w, int p) { return (int)((w >> (8 * p)) & 0xffu); }
 
-    auto load3 = [&](int y, uint32_t (&r)[3]) {
-        const bool rv = y >= 0 && y < H;
-        const uint32_t *rp = p + (size_t)(rv ? y : 0) * W;
-        const uint32_t a = rp[lin ? xc - 1 : xc], b = rp[xc], c = rp[rin ? xc + 1 : xc];
-        r[0] = (rv && lin) ? a : 0u;
-        r[1] = (rv && xin) ? b : 0u;
-        r[2] = (rv && rin) ? c : 0u;
+// lane i <- lane i-1 (wave_shr:1) / lane i+1 (wave_shl:1); lanes without a source keep `old`
+__device__ __forceinline__ int from_left(int old, int v)
+{
+    return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int from_right(int old, int v)
+{
+    return __builtin_amdgcn_update_dpp(old, v, 0x130, 0xf, 0xf, false);
+}
+// OR over aligned groups of 8 lanes (result in every lane of the group)
+__device__ __forceinline__ uint32_t or8(uint32_t x)
+{
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, true);   // row_half_mirror
+    return x;
+}
+
+constexpr int DETECT_ROWS = 32;                       // rows per strip
+constexpr int DETECT_QUEUE = 256 * DETECT_ROWS / 4;   // strict extrema are never 8-adjacent
+
+struct ColStat { int e0, e1, f0, f1, b0, b1; };       // rows y-1 (0) and y (1) of one column
+
+// grid: x = ceil(W/256) spans, y = strips of DETECT_ROWS, z = frames; block = 64 (one wave)
+template <bool FULLGRAD>
+__global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, const uint4 *__restrict__ zero_row,
+                                               u64 *__restrict__ premask, u64 *__restrict__ candmask,
+                                               u64 *__restrict__ survmask, uint32_t *__restrict__ rowcount,
+                                               uint32_t *__restrict__ list, uint32_t *__restrict__ listcount,
+                                               uint16_t *__restrict__ gradp, uint32_t *__restrict__ gradfull,
+                                               int W, int H, int S, int contrastTh, int list_cap)
+{
+    __shared__ uint32_t queue[DETECT_QUEUE];
+
+    const int lane = threadIdx.x;
+    const int W4 = W >> 2;
+    const int g = blockIdx.x * 64 + lane;             // 4-pixel group of this lane
+    const int ys = blockIdx.y * DETECT_ROWS;
+    const int ye = min(H, ys + DETECT_ROWS);
+    const int frame = blockIdx.z;
+    const size_t fpix = (size_t)frame * (size_t)W * (size_t)H;
+    const uint4 *__restrict__ fp = pyr + (fpix >> 2);
+
+    const bool colvalid = g < W4;
+    const uint32_t cmask = colvalid ? 0xffffffffu : 0u;
+    const uint32_t gc = colvalid ? (uint32_t)g : 0u;
+    // halo column: the pixel left of the wave for lane 0, right of it for lane 63
+    const int gh = lane == 0 ? g - 1 : g + 1;
+    const bool hvalid = gh >= 0 && gh < W4;
+    const uint32_t hmask = hvalid ? 0xffffffffu : 0u;
+    const uint32_t ghc = hvalid ? (uint32_t)gh : 0u;
+    const int hp = lane == 0 ? 3 : 0;                 // its pixel inside that group
+
+    auto load_row = [&](int r, uint4 &Q, uint4 &Qh) {
+        const uint4 *rp = (r >= 0 && r < H) ? fp + (size_t)r * W4 : zero_row;   // wave-uniform
+        Q = rp[gc];
+        Qh = rp[ghc];
+    };
+    auto masked = [](uint4 q, uint32_t m) { q.x &= m; q.y &= m; q.z &= m; q.w &= m; return q; };
+
+    ColStat st[4], hs;
+    uint32_t g2a = 0, g2b = 0, hg2b = 0;              // G2 dwords of rows y-1, y; halo group's G2 of row y
+    auto stats = [&](const uint4 &Q, int p, int &e, int &f, int &b) {
+        const int d1 = byte_of(Q.y, p) - byte_of(Q.x, p);
+        const int d3 = byte_of(Q.w, p) - byte_of(Q.z, p);
+        b = byte_of(Q.z, p) - byte_of(Q.y, p);
+        e = max(d1, d3);
+        f = min(d1, d3);
+    };
+    // push row r into the state (rows shift up by one)
+    auto advance = [&](const uint4 &Q, const uint4 &Qh, int (&e2)[4], int (&f2)[4], int (&b2)[4], int &he2, int &hf2,
+                       int &hb2) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) stats(Q, p, e2[p], f2[p], b2[p]);
+        // halo pixel: byte hp of each plane
+        const uint32_t sh = (uint32_t)hp * 8u;
+        const int hsrc = (int)((Qh.x >> sh) & 0xffu), h1 = (int)((Qh.y >> sh) & 0xffu);
+        const int h2 = (int)((Qh.z >> sh) & 0xffu), h3 = (int)((Qh.w >> sh) & 0xffu);
+        const int hd1 = h1 - hsrc, hd3 = h3 - h2;
+        hb2 = h2 - h1;
+        he2 = max(hd1, hd3);
+        hf2 = min(hd1, hd3);
+    };
+    auto shift_in = [&](const int (&e2)[4], const int (&f2)[4], const int (&b2)[4], int he2, int hf2, int hb2) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            st[p].e0 = st[p].e1; st[p].e1 = e2[p];
+            st[p].f0 = st[p].f1; st[p].f1 = f2[p];
+            st[p].b0 = st[p].b1; st[p].b1 = b2[p];
+        }
+        hs.e0 = hs.e1; hs.e1 = he2; hs.f0 = hs.f1; hs.f1 = hf2; hs.b0 = hs.b1; hs.b1 = hb2;
     };
 
-    uint32_t r0[3], r1[3], r2[3];
-    load3(ys - 1, r0);
-    load3(ys, r1);
+    // prologue: rows ys-1 and ys
+    uint4 Q, Qh, Qn, Qhn;
+    {
+        int e2[4], f2[4], b2[4], he2, hf2, hb2;
+#pragma unroll
+        for (int p = 0; p < 4; p++) st[p] = ColStat{0, 0, 0, 0, 0, 0};
+        hs = ColStat{0, 0, 0, 0, 0, 0};
+        load_row(ys - 1, Q, Qh);
+        Q = masked(Q, cmask); Qh = masked(Qh, hmask);
+        advance(Q, Qh, e2, f2, b2, he2, hf2, hb2);
+        shift_in(e2, f2, b2, he2, hf2, hb2);
+        g2b = Q.z;
+        load_row(ys, Q, Qh);
+        Q = masked(Q, cmask); Qh = masked(Qh, hmask);
+        advance(Q, Qh, e2, f2, b2, he2, hf2, hb2);
+        shift_in(e2, f2, b2, he2, hf2, hb2);
+        g2a = g2b; g2b = Q.z; hg2b = Qh.z;
+    }
+    load_row(ys + 1, Qn, Qhn);
+
+    uint32_t qcount = 0;                              // wave-uniform
+    const size_t frow = (size_t)frame * H;
     for (int y = ys; y < ye; ++y) {
-        load3(y + 1, r2);
-        const int c = pyr_d2(r1[1]);
-        const int ac = c < 0 ? -c : c;
+        Q = masked(Qn, cmask); Qh = masked(Qhn, hmask);                 // row y+1
+        load_row(y + 2, Qn, Qhn);                                        // prefetch (a row past the strip is harmless)
 
-        // strict 26-neighbour extremum (:245-304)
-        int mx = -1024, mn = 1024;
-        auto acc3 = [&](uint32_t w) {
-            const int a = pyr_d1(w), b = pyr_d3(w);
-            mx = max(mx, max(a, b));
-            mn = min(mn, min(a, b));
-        };
-        auto acc2 = [&](uint32_t w) {
-            const int m = pyr_d2(w);
-            mx = max(mx, m);
-            mn = min(mn, m);
-        };
+        int e2[4], f2[4], b2[4], he2, hf2, hb2;
+        advance(Q, Qh, e2, f2, b2, he2, hf2, hb2);
+
+        // per column: max/min over the three rows
+        int E[4], F[4], BA[4], BI[4];
 #pragma unroll
-        for (int k = 0; k < 3; k++) { acc3(r0[k]); acc3(r1[k]); acc3(r2[k]); }
-        acc2(r0[0]); acc2(r0[1]); acc2(r0[2]); acc2(r1[0]); acc2(r1[2]); acc2(r2[0]); acc2(r2[1]); acc2(r2[2]);
-        const bool ext = (c > mx) || (c < mn);
-
-        bool cand = false;
-        int e = -1;
-        if (xin && ext && ac >= contrastTh) {        // :194, :200
-            e = edge_ratio_q15(pyr_d2(r1[0]), pyr_d2(r1[2]), pyr_d2(r0[1]), pyr_d2(r2[1]),
-                               pyr_d2(r0[0]), pyr_d2(r0[2]), pyr_d2(r2[0]), pyr_d2(r2[2]), c);
-            cand = (e >= 0) && (ac > 0);             // kpOut = |c| must be non-zero to count (:684)
+        for (int p = 0; p < 4; p++) {
+            E[p] = max(max(st[p].e0, st[p].e1), e2[p]);
+            F[p] = min(min(st[p].f0, st[p].f1), f2[p]);
+            BA[p] = max(max(st[p].b0, st[p].b1), b2[p]);
+            BI[p] = min(min(st[p].b0, st[p].b1), b2[p]);
         }
-        const unsigned long long bal = __ballot(cand);
-        const size_t row = (size_t)blockIdx.z * H + y;
-        if ((threadIdx.x & 63) == 0) candmask[row * S + seg] = bal;
-        if (cand) keyplane[fpix + (size_t)y * W + x] = ((uint32_t)e << 8) | (uint32_t)ac;
+        const int hE = max(max(hs.e0, hs.e1), he2), hF = min(min(hs.f0, hs.f1), hf2);
+        const int hBA = max(max(hs.b0, hs.b1), hb2), hBI = min(min(hs.b0, hs.b1), hb2);
+        const int lE = from_left(hE, E[3]), lF = from_left(hF, F[3]);
+        const int lBA = from_left(hBA, BA[3]), lBI = from_left(hBI, BI[3]);
+        const int rE = from_right(hE, E[0]), rF = from_right(hF, F[0]);
+        const int rBA = from_right(hBA, BA[0]), rBI = from_right(hBI, BI[0]);
 
-        // gradient of G2 (:1189-1190)
-        if (xin) {
-            int ang, mag;
-            grad_code(pyr_g2(r1[2]) - pyr_g2(r1[0]), pyr_g2(r2[1]) - pyr_g2(r0[1]), ang, mag);
-            gradp[fpix + (size_t)y * W + x] = (uint16_t)gradp_pack(ang, mag);
-            if constexpr (FULLGRAD) gradfull[fpix + (size_t)y * W + x] = (uint32_t)ang | ((uint32_t)mag << 16);
-        }
+        bool pre[4];
+        uint32_t nib = 0;
 #pragma unroll
-        for (int k = 0; k < 3; k++) { r0[k] = r1[k]; r1[k] = r2[k]; }
+        for (int p = 0; p < 4; p++) {
+            const int El = p ? E[p - 1] : lE, Er = p < 3 ? E[p + 1] : rE;
+            const int Fl = p ? F[p - 1] : lF, Fr = p < 3 ? F[p + 1] : rF;
+            const int BAl = p ? BA[p - 1] : lBA, BAr = p < 3 ? BA[p + 1] : rBA;
+            const int BIl = p ? BI[p - 1] : lBI, BIr = p < 3 ? BI[p + 1] : rBI;
+            const int c = st[p].b1;
+            const int mx = max(max(max(El, E[p]), Er), max(max(BAl, BAr), max(st[p].b0, b2[p])));
+            const int mn = min(min(min(Fl, F[p]), Fr), min(min(BIl, BIr), min(st[p].b0, b2[p])));
+            const int ac = c < 0 ? -c : c;
+            // strict 26-neighbour extremum (:245-304), |D2| >= contrastTh (:194), kpOut = |c| non-zero (:684)
+            pre[p] = colvalid && ((c > mx) || (c < mn)) && ac >= contrastTh && ac > 0;
+            nib |= pre[p] ? (1u << p) : 0u;
+        }
+
+        // raster mask: 8 lanes = 32 columns = one dword
+        const bool anypre = __ballot(nib != 0) != 0ull;
+        {
+            uint32_t word = 0;
+            if (anypre) word = or8(nib << (4 * (lane & 7)));
+            const int wi = blockIdx.x * 8 + (lane >> 3);          // dword index in the row
+            if ((lane & 7) == 7 && wi < 2 * S) reinterpret_cast<uint32_t *>(premask + (frow + y) * S)[wi] = word;
+            // k_cand sets bits in these with atomics
+            const int s64 = blockIdx.x * 4 + lane;
+            if (lane < 4 && s64 < S) { candmask[(frow + y) * S + s64] = 0ull; survmask[(frow + y) * S + s64] = 0ull; }
+            if (blockIdx.x == 0 && lane == 0) rowcount[frow + y] = 0u;
+        }
+        if (anypre) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const u64 bal = __ballot(pre[p]);
+                if (bal) {
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    if (pre[p] && qcount + below < (uint32_t)DETECT_QUEUE) queue[qcount + below] = ((uint32_t)y << 16) | (uint32_t)(g * 4 + p);
+                    qcount += (uint32_t)__popcll(bal);
+                }
+            }
+        }
+
+        // gradient of G2 at row y (:1189-1190): gx from the row itself, gy from rows y-1 and y+1
+        // (the DPP shifts run with every lane active: a disabled source lane would leave `old`)
+        const uint32_t lw = (uint32_t)from_left((int)hg2b, (int)g2b);         // G2 dword of the group to the left
+        const uint32_t rw = (uint32_t)from_right((int)hg2b, (int)g2b);
+        if (colvalid) {
+            uint32_t gp[4], gf[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const int right = p < 3 ? byte_of(g2b, p + 1) : byte_of(rw, 0);
+                const int left = p ? byte_of(g2b, p - 1) : byte_of(lw, 3);
+                const int gx = right - left;
+                const int gy = byte_of(Q.z, p) - byte_of(g2a, p);
+                int ang, mag;
+                grad_code(gx, gy, ang, mag);
+                gp[p] = gradp_pack(ang, mag);
+                gf[p] = (uint32_t)ang | ((uint32_t)mag << 16);            // Grad_t {angGrad, magGrad}
+            }
+            if constexpr (FULLGRAD)
+                *reinterpret_cast<uint4 *>(gradfull + fpix + (size_t)y * W + (size_t)g * 4) = make_uint4(gf[0], gf[1], gf[2], gf[3]);
+            uint2 o;
+            o.x = gp[0] | (gp[1] << 16);
+            o.y = gp[2] | (gp[3] << 16);
+            *reinterpret_cast<uint2 *>(gradp + fpix + (size_t)y * W + (size_t)g * 4) = o;
+        }
+
+        shift_in(e2, f2, b2, he2, hf2, hb2);
+        g2a = g2b; g2b = Q.z; hg2b = Qh.z;
+    }
+
+    // flush the strip's queue to the frame's list
+    __syncthreads();
+    if (qcount) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(listcount + frame, qcount);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        uint32_t *__restrict__ fl = list + (size_t)frame * list_cap;
+        for (uint32_t i = lane; i < qcount; i += 64)
+            if (base + i < (uint32_t)list_cap) fl[base + i] = queue[i];
     }
 }
 

@@ -44,8 +44,8 @@ int fail(int code, const char *what, hipError_t e = hipSuccess)
         if (e_ != hipSuccess) return fail(SIFT_HIP_EHIP, #expr, e_); \
     } while (0)
 
-enum { ST_BLUR = 0, ST_DETECT, ST_CULL, ST_EMIT, ST_DESCRIBE };
-const char *const kStageNames[SIFT_HIP_NSTAGES] = {"k_blur", "k_detect", "k_cull", "k_emit", "k_describe"};
+enum { ST_BLUR = 0, ST_DETECT, ST_CAND, ST_EMIT, ST_DESCRIBE };
+const char *const kStageNames[SIFT_HIP_NSTAGES] = {"k_blur", "k_detect", "k_cand", "k_emit", "k_describe"};
 
 // Union-pixel table of the 71x71 descriptor window for frames `W` wide (see
 // describe_kernel.h): two-circle pixels first (n2, padded to n2pad), then the rest.
@@ -164,8 +164,11 @@ struct sift_hip_ctx {
     hipStream_t stream = nullptr;
     // persistent scratch, max_batch frames each
     uint8_t *d_img = nullptr;             // staging for host-buffer entry points
-    uint32_t *d_pyr = nullptr;            // src|G1|G2|G3 per pixel
-    unsigned long long *d_cand = nullptr, *d_surv = nullptr;   // [H][S] ballots
+    uint4 *d_pyr = nullptr;               // {src, G1, G2, G3} dwords per group of 4 pixels
+    uint4 *d_zero = nullptr;              // a row of zeros (4*W bytes): rows outside the image
+    unsigned long long *d_pre = nullptr, *d_cand = nullptr, *d_surv = nullptr;   // [H][S] bit masks
+    uint32_t *d_list = nullptr, *d_listcount = nullptr;        // k_detect's pixel list per frame
+    int list_cap = 0;
     uint32_t *d_key = nullptr;            // (E<<8)|contrast at candidates
     uint32_t *d_rowcount = nullptr;       // [H]
     uint16_t *d_gradp = nullptr;          // (ang<<12)|mag
@@ -232,30 +235,35 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
 {
     const int W = c->W, H = c->H, S = c->S;
     c->last_frames = nframes;
+    HIP_TRY(hipMemsetAsync(c->d_listcount, 0, (size_t)nframes * 4, s));
     {
         StageTimer t(c, ST_BLUR, s);
         const int rows = pick_blur_rows(c, nframes);
-        dim3 grid(((W / 4) + 255) / 256, (H + rows - 1) / rows, nframes);
         // 64-thread blocks when a row has few dword columns, so small frames still spread over CUs
         const int bs = (W / 4) >= 256 ? 256 : 64;
-        grid.x = ((W / 4) + bs - 1) / bs;
-        hipLaunchKernelGGL(sift::k_blur<true>, grid, dim3(bs), 0, s, d_imgs, c->d_pyr, W, H, rows);
+        dim3 grid(((W / 4) + bs - 1) / bs, (H + rows - 1) / rows, nframes);
+        hipLaunchKernelGGL(sift::k_blur<true>, grid, dim3(bs), 0, s, d_imgs, c->d_pyr,
+                           reinterpret_cast<const uint32_t *>(c->d_zero), W, H, rows);
     }
     {
         StageTimer t(c, ST_DETECT, s);
-        const int rows = 16;
-        dim3 grid((W + 255) / 256, (H + rows - 1) / rows, nframes);
+        dim3 grid((W + 255) / 256, (H + sift::DETECT_ROWS - 1) / sift::DETECT_ROWS, nframes);
         if (d_gradfull)
-            hipLaunchKernelGGL(sift::k_detect<true>, grid, dim3(256), 0, s, c->d_pyr, c->d_cand, c->d_key,
-                               c->d_gradp, d_gradfull, W, H, S, rows, th);
+            hipLaunchKernelGGL(sift::k_detect<true>, grid, dim3(64), 0, s, c->d_pyr, c->d_zero, c->d_pre, c->d_cand,
+                               c->d_surv, c->d_rowcount, c->d_list, c->d_listcount, c->d_gradp, d_gradfull, W, H, S,
+                               th, c->list_cap);
         else
-            hipLaunchKernelGGL(sift::k_detect<false>, grid, dim3(256), 0, s, c->d_pyr, c->d_cand, c->d_key,
-                               c->d_gradp, (uint32_t *)nullptr, W, H, S, rows, th);
+            hipLaunchKernelGGL(sift::k_detect<false>, grid, dim3(64), 0, s, c->d_pyr, c->d_zero, c->d_pre, c->d_cand,
+                               c->d_surv, c->d_rowcount, c->d_list, c->d_listcount, c->d_gradp,
+                               (uint32_t *)nullptr, W, H, S, th, c->list_cap);
     }
     {
-        StageTimer t(c, ST_CULL, s);
-        dim3 grid((H + 3) / 4, nframes);
-        hipLaunchKernelGGL(sift::k_cull, grid, dim3(256), 0, s, c->d_cand, c->d_key, c->d_surv, c->d_rowcount, W, H, S);
+        StageTimer t(c, ST_CAND, s);
+        // grid-stride over the list; ~1 % of the pixels are listed
+        const int blocks = (int)std::min<size_t>(1024, (c->npix / 64 + 255) / 256 + 1);
+        dim3 grid(blocks, nframes);
+        hipLaunchKernelGGL(sift::k_cand, grid, dim3(256), 0, s, c->d_pyr, c->d_pre, c->d_list, c->d_listcount,
+                           c->d_cand, c->d_surv, c->d_key, c->d_rowcount, W, H, S, c->list_cap);
     }
     {
         StageTimer t(c, ST_EMIT, s);
@@ -358,6 +366,12 @@ int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int m
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     A((void **)&c->d_img, B * np);
     A((void **)&c->d_pyr, B * np * 4);
+    A((void **)&c->d_zero, (size_t)width * 4 + 64);
+    if (e == hipSuccess) e = hipMemset(c->d_zero, 0, (size_t)width * 4 + 64);
+    c->list_cap = (int)std::min<size_t>(np / 2 + 64, 0x7fffffff);
+    A((void **)&c->d_list, B * (size_t)c->list_cap * 4);
+    A((void **)&c->d_listcount, B * 4);
+    A((void **)&c->d_pre, B * HS * 8);
     A((void **)&c->d_cand, B * HS * 8);
     A((void **)&c->d_surv, B * HS * 8);
     A((void **)&c->d_key, B * np * 4);
@@ -386,7 +400,7 @@ void sift_hip_destroy(sift_hip_ctx *c)
     if (!c) return;
     DevGuard g(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->d_img, c->d_pyr, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_gradp,
+    void *ptrs[] = {c->d_img, c->d_pyr, c->d_zero, c->d_list, c->d_listcount, c->d_pre, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_gradp,
                     c->d_gradfull, c->d_kps, c->d_desc, c->d_total, c->d_ori, c->d_tab, c->d_qtab};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &ps : c->prof)
@@ -636,12 +650,14 @@ int sift_hip_debug_planes(sift_hip_ctx *c, int frame, uint8_t *g1, uint8_t *g2, 
     HIP_TRY(hipDeviceSynchronize());
     const size_t np = c->npix;
     if (g1 || g2 || g3) {
-        std::vector<uint32_t> pyr(np);
-        HIP_TRY(hipMemcpy(pyr.data(), c->d_pyr + (size_t)frame * np, np * 4, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> pyr(np);    // per group of 4 pixels: src, G1, G2, G3 dwords
+        HIP_TRY(hipMemcpy(pyr.data(), c->d_pyr + (size_t)frame * (np / 4), np * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < np; i++) {
-            if (g1) g1[i] = (uint8_t)(pyr[i] >> 8);
-            if (g2) g2[i] = (uint8_t)(pyr[i] >> 16);
-            if (g3) g3[i] = (uint8_t)(pyr[i] >> 24);
+            const size_t q = (i >> 2) * 4;
+            const int sh = (int)(i & 3) * 8;
+            if (g1) g1[i] = (uint8_t)(pyr[q + 1] >> sh);
+            if (g2) g2[i] = (uint8_t)(pyr[q + 2] >> sh);
+            if (g3) g3[i] = (uint8_t)(pyr[q + 3] >> sh);
         }
     }
     if (cand || eratio || surv) {
