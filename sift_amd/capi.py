@@ -96,4 +96,4 @@ def check(rc):
     return rc
 
 
-STAGE_NAMES = ("k_blur", "k_detect", "k_cand", "k_emit", "k_describe")
+STAGE_NAMES = ("k_blur", "k_detect", "k_cull", "k_emit", "k_describe")

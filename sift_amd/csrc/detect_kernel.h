@@ -1,9 +1,9 @@
-// detect_kernel.h -- DoG, 3x3x3 extremum, contrast test and the gradient plane, from the planar
-// "pyr" words written by k_blur.
+// detect_kernel.h -- DoG, 3x3x3 extremum, contrast and edge tests and the gradient plane, from
+// the planar "pyr" words written by k_blur.
 //
-// Restates build_DOG_hls (DetectKeypoints.cpp:511-559), detect_extrema_hls + IsLocalExtremum
-// (:44-223, :234-308, without the edge test, which k_cand applies to the few pixels that get
-// this far) and ComputeGradientsHLS + ComputeGradientKernel (:1273-1363, :1186-1225).
+// Restates build_DOG_hls (DetectKeypoints.cpp:511-559), detect_extrema_hls + IsLocalExtremum +
+// IsOnEdge (:44-223, :234-308, :314-352) and ComputeGradientsHLS + ComputeGradientKernel
+// (:1273-1363, :1186-1225).
 //
 // A lane owns 4 adjacent pixels (one uint4 of pyr = src, G1, G2, G3 dwords) and walks down
 // `rows` image rows; a wave covers 256 columns.  The DoG planes are never materialised:
@@ -17,12 +17,17 @@
 // DPP wave shifts for the outer ones; lanes 0 and 63 compute the one column beyond the wave
 // themselves (the "halo" column; the DPP shift leaves their `old` value in place).
 //
+// Pixels that pass the extremum and contrast tests (~1 %) are queued in LDS; at the end of the
+// strip the wave runs the edge test (the one float divide of the path) on the queue, one lane per
+// entry, and what passes is a pre-cull candidate (kpMap1 != 0, :190-207).
+//
 // Outputs per frame
-//   premask[y][seg]   u64, bit = pixel is a strict extremum with |D2| >= contrastTh (raster order)
-//   list[]            the same pixels as (y << 16 | x), appended per strip (order irrelevant)
+//   candmask[y][seg]  u64, bit = pre-cull candidate (raster order; every word of the strip written)
+//   keyplane[y][x]    u32, written ONLY at candidates: (E_q15 << 8) | |D2|
+//   list[]            the candidates as (y << 16 | x), appended per strip (order irrelevant)
 //   gradp[y][x]       u16 mag | (code-1) << 9, 0 for code 0   (internal, 2 B/pixel)
 //   gradfull[y][x]    Grad_t {ang, mag}                        (optional, sift_detect API)
-// and it zeroes candmask / survmask / rowcount, which k_cand fills with atomics.
+// and it zeroes survmask / rowcount, which k_cull fills with atomics.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -74,6 +79,49 @@ __device__ __forceinline__ uint32_t or8(uint32_t x)
     return x;
 }
 
+// D2 = G2 - G1 at (y, x) from the planar pyr plane, 0 outside the image.  Branch-free (clamped
+// address, masked result) so that the nine calls of one edge test load in parallel.
+__device__ __forceinline__ int pyr_d2_at(const uint4 *__restrict__ fp, int W4, int W, int H, int y, int x)
+{
+    const bool ok = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    const int yc = ok ? y : 0, xc = ok ? x : 0;
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(fp + (size_t)yc * W4 + (xc >> 2));
+    const uint32_t g1 = q[1], g2 = q[2];
+    const int sh = (xc & 3) * 8;
+    const int d = (int)((g2 >> sh) & 0xffu) - (int)((g1 >> sh) & 0xffu);
+    return ok ? d : 0;
+}
+
+// IsOnEdge (:314-352) + float -> ap_fixed<32,17,AP_RND_ZERO>: Q15 ratio or -1.
+__device__ __forceinline__ int edge_ratio_q15(int L, int R, int U, int Dn, int UL, int UR, int DL, int DR, int c)
+{
+    const int fxx = L + R - 2 * c;
+    const int fyy = U + Dn - 2 * c;
+    const int fxy = UL + DR - DL - UR;
+    const int tr = fxx + fyy;
+    const int det = fxx * fyy - fxy * fxy;
+    if (det == 0) return -1;
+    // both operands are exact in binary32 (|.| < 2^24); __fdiv_rn is the IEEE
+    // correctly rounded divide whatever the fast-math flags are
+    const float r = __fdiv_rn((float)(tr * tr), (float)det);
+    if (r < 0.0f || r > 12.0f) return -1;            // EIGEN_RATIO_TH, DetectKeypoints.hpp:18
+    // r * 2^15 is exact in binary32 (r <= 12); round to nearest, ties toward zero
+    const float v = r * 32768.0f;
+    const float fl = floorf(v);
+    return (int)fl + ((v - fl) > 0.5f ? 1 : 0);
+}
+
+// Q15 edge ratio of the pixel (y, x), -1 if the edge test rejects it; *contrast = |D2|
+__device__ __forceinline__ int edge_at(const uint4 *__restrict__ fp, int W4, int W, int H, int y, int x, int *contrast)
+{
+    const int c = pyr_d2_at(fp, W4, W, H, y, x);
+    if (contrast) *contrast = c < 0 ? -c : c;
+    return edge_ratio_q15(pyr_d2_at(fp, W4, W, H, y, x - 1), pyr_d2_at(fp, W4, W, H, y, x + 1),
+                          pyr_d2_at(fp, W4, W, H, y - 1, x), pyr_d2_at(fp, W4, W, H, y + 1, x),
+                          pyr_d2_at(fp, W4, W, H, y - 1, x - 1), pyr_d2_at(fp, W4, W, H, y - 1, x + 1),
+                          pyr_d2_at(fp, W4, W, H, y + 1, x - 1), pyr_d2_at(fp, W4, W, H, y + 1, x + 1), c);
+}
+
 constexpr int DETECT_ROWS = 32;                       // rows per strip
 constexpr int DETECT_QUEUE = 256 * DETECT_ROWS / 4;   // strict extrema are never 8-adjacent
 
@@ -82,13 +130,14 @@ struct ColStat { int e0, e1, f0, f1, b0, b1; };       // rows y-1 (0) and y (1) 
 // grid: x = ceil(W/256) spans, y = strips of DETECT_ROWS, z = frames; block = 64 (one wave)
 template <bool FULLGRAD>
 __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, const uint4 *__restrict__ zero_row,
-                                               u64 *__restrict__ premask, u64 *__restrict__ candmask,
+                                               u64 *__restrict__ candmask, uint32_t *__restrict__ keyplane,
                                                u64 *__restrict__ survmask, uint32_t *__restrict__ rowcount,
                                                uint32_t *__restrict__ list, uint32_t *__restrict__ listcount,
                                                uint16_t *__restrict__ gradp, uint32_t *__restrict__ gradfull,
                                                int W, int H, int S, int contrastTh, int list_cap)
 {
     __shared__ uint32_t queue[DETECT_QUEUE];
+    __shared__ u64 cmap[DETECT_ROWS * 4];             // candidate bits of the strip: row-major, 4 words per row
 
     const int lane = threadIdx.x;
     const int W4 = W >> 2;
@@ -99,6 +148,9 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
     const size_t fpix = (size_t)frame * (size_t)W * (size_t)H;
     const uint4 *__restrict__ fp = pyr + (fpix >> 2);
 
+    cmap[lane] = 0ull;
+    cmap[lane + 64] = 0ull;
+    __syncthreads();
     const bool colvalid = g < W4;
     const uint32_t cmask = colvalid ? 0xffffffffu : 0u;
     const uint32_t gc = colvalid ? (uint32_t)g : 0u;
@@ -170,7 +222,6 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
     load_row(ys + 1, Qn, Qhn);
 
     uint32_t qcount = 0;                              // wave-uniform
-    const size_t frow = (size_t)frame * H;
     for (int y = ys; y < ye; ++y) {
         Q = masked(Qn, cmask); Qh = masked(Qhn, hmask);                 // row y+1
         load_row(y + 2, Qn, Qhn);                                        // prefetch (a row past the strip is harmless)
@@ -211,18 +262,7 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
             nib |= pre[p] ? (1u << p) : 0u;
         }
 
-        // raster mask: 8 lanes = 32 columns = one dword
         const bool anypre = __ballot(nib != 0) != 0ull;
-        {
-            uint32_t word = 0;
-            if (anypre) word = or8(nib << (4 * (lane & 7)));
-            const int wi = blockIdx.x * 8 + (lane >> 3);          // dword index in the row
-            if ((lane & 7) == 7 && wi < 2 * S) reinterpret_cast<uint32_t *>(premask + (frow + y) * S)[wi] = word;
-            // k_cand sets bits in these with atomics
-            const int s64 = blockIdx.x * 4 + lane;
-            if (lane < 4 && s64 < S) { candmask[(frow + y) * S + s64] = 0ull; survmask[(frow + y) * S + s64] = 0ull; }
-            if (blockIdx.x == 0 && lane == 0) rowcount[frow + y] = 0u;
-        }
         if (anypre) {
 #pragma unroll
             for (int p = 0; p < 4; p++) {
@@ -265,14 +305,43 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
         g2a = g2b; g2b = Q.z; hg2b = Qh.z;
     }
 
-    // flush the strip's queue to the frame's list
+    // edge test on the queue, one lane per entry; survivors of it are compacted in place
     __syncthreads();
-    if (qcount) {
+    const size_t frow = (size_t)frame * H;
+    uint32_t ccount = 0;                              // wave-uniform
+    for (uint32_t i0 = 0; i0 < qcount; i0 += 64) {
+        const bool live = i0 + lane < qcount;
+        const uint32_t e = live ? queue[i0 + lane] : 0u;
+        const int y = (int)(e >> 16), x = (int)(e & 0xffffu);
+        int ac;
+        const int ec = edge_at(fp, W4, W, H, y, x, &ac);
+        const bool cand = live && ec >= 0;                           // :200
+        if (cand) {
+            keyplane[fpix + (size_t)y * W + x] = ((uint32_t)ec << 8) | (uint32_t)ac;
+            atomicOr(&cmap[(y - ys) * 4 + ((x >> 6) & 3)], 1ull << (x & 63));
+        }
+        const u64 bal = __ballot(cand);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (cand) queue[ccount + below] = e;          // ccount + below <= i0 + lane: nothing unread is overwritten
+        ccount += (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+    // every mask word of the strip: candidates as found, survivors empty (k_cull sets them)
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int wi = lane + 64 * k, row = wi >> 2, seg = blockIdx.x * 4 + (wi & 3);
+        if (ys + row < ye && seg < S) {
+            candmask[(frow + ys + row) * S + seg] = cmap[wi];
+            survmask[(frow + ys + row) * S + seg] = 0ull;
+        }
+    }
+    if (blockIdx.x == 0 && lane < ye - ys) rowcount[frow + ys + lane] = 0u;
+    if (ccount) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(listcount + frame, qcount);
+        if (lane == 0) base = atomicAdd(listcount + frame, ccount);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         uint32_t *__restrict__ fl = list + (size_t)frame * list_cap;
-        for (uint32_t i = lane; i < qcount; i += 64)
+        for (uint32_t i = lane; i < ccount; i += 64)
             if (base + i < (uint32_t)list_cap) fl[base + i] = queue[i];
     }
 }

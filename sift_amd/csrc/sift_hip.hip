@@ -44,8 +44,8 @@ int fail(int code, const char *what, hipError_t e = hipSuccess)
         if (e_ != hipSuccess) return fail(SIFT_HIP_EHIP, #expr, e_); \
     } while (0)
 
-enum { ST_BLUR = 0, ST_DETECT, ST_CAND, ST_EMIT, ST_DESCRIBE };
-const char *const kStageNames[SIFT_HIP_NSTAGES] = {"k_blur", "k_detect", "k_cand", "k_emit", "k_describe"};
+enum { ST_BLUR = 0, ST_DETECT, ST_CULL, ST_EMIT, ST_DESCRIBE };
+const char *const kStageNames[SIFT_HIP_NSTAGES] = {"k_blur", "k_detect", "k_cull", "k_emit", "k_describe"};
 
 // Union-pixel table of the 71x71 descriptor window for frames `W` wide (see
 // describe_kernel.h): two-circle pixels first (n2, padded to n2pad), then the rest.
@@ -166,8 +166,8 @@ struct sift_hip_ctx {
     uint8_t *d_img = nullptr;             // staging for host-buffer entry points
     uint4 *d_pyr = nullptr;               // {src, G1, G2, G3} dwords per group of 4 pixels
     uint4 *d_zero = nullptr;              // a row of zeros (4*W bytes): rows outside the image
-    unsigned long long *d_pre = nullptr, *d_cand = nullptr, *d_surv = nullptr;   // [H][S] bit masks
-    uint32_t *d_list = nullptr, *d_listcount = nullptr;        // k_detect's pixel list per frame
+    unsigned long long *d_cand = nullptr, *d_surv = nullptr;   // [H][S] bit masks
+    uint32_t *d_list = nullptr, *d_listcount = nullptr;        // k_detect's candidate list per frame
     int list_cap = 0;
     uint32_t *d_key = nullptr;            // (E<<8)|contrast at candidates
     uint32_t *d_rowcount = nullptr;       // [H]
@@ -249,21 +249,21 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
         StageTimer t(c, ST_DETECT, s);
         dim3 grid((W + 255) / 256, (H + sift::DETECT_ROWS - 1) / sift::DETECT_ROWS, nframes);
         if (d_gradfull)
-            hipLaunchKernelGGL(sift::k_detect<true>, grid, dim3(64), 0, s, c->d_pyr, c->d_zero, c->d_pre, c->d_cand,
+            hipLaunchKernelGGL(sift::k_detect<true>, grid, dim3(64), 0, s, c->d_pyr, c->d_zero, c->d_cand, c->d_key,
                                c->d_surv, c->d_rowcount, c->d_list, c->d_listcount, c->d_gradp, d_gradfull, W, H, S,
                                th, c->list_cap);
         else
-            hipLaunchKernelGGL(sift::k_detect<false>, grid, dim3(64), 0, s, c->d_pyr, c->d_zero, c->d_pre, c->d_cand,
+            hipLaunchKernelGGL(sift::k_detect<false>, grid, dim3(64), 0, s, c->d_pyr, c->d_zero, c->d_cand, c->d_key,
                                c->d_surv, c->d_rowcount, c->d_list, c->d_listcount, c->d_gradp,
                                (uint32_t *)nullptr, W, H, S, th, c->list_cap);
     }
     {
-        StageTimer t(c, ST_CAND, s);
-        // grid-stride over the list; ~1 % of the pixels are listed
-        const int blocks = (int)std::min<size_t>(1024, (c->npix / 64 + 255) / 256 + 1);
+        StageTimer t(c, ST_CULL, s);
+        // grid-stride over the candidate list (~0.6 % of the pixels)
+        const int blocks = (int)std::min<size_t>(1024, (c->npix / 128 + 255) / 256 + 1);
         dim3 grid(blocks, nframes);
-        hipLaunchKernelGGL(sift::k_cand, grid, dim3(256), 0, s, c->d_pyr, c->d_pre, c->d_list, c->d_listcount,
-                           c->d_cand, c->d_surv, c->d_key, c->d_rowcount, W, H, S, c->list_cap);
+        hipLaunchKernelGGL(sift::k_cull, grid, dim3(256), 0, s, c->d_cand, c->d_key, c->d_list, c->d_listcount,
+                           c->d_surv, c->d_rowcount, W, H, S, c->list_cap);
     }
     {
         StageTimer t(c, ST_EMIT, s);
@@ -371,7 +371,6 @@ int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int m
     c->list_cap = (int)std::min<size_t>(np / 2 + 64, 0x7fffffff);
     A((void **)&c->d_list, B * (size_t)c->list_cap * 4);
     A((void **)&c->d_listcount, B * 4);
-    A((void **)&c->d_pre, B * HS * 8);
     A((void **)&c->d_cand, B * HS * 8);
     A((void **)&c->d_surv, B * HS * 8);
     A((void **)&c->d_key, B * np * 4);
@@ -400,7 +399,7 @@ void sift_hip_destroy(sift_hip_ctx *c)
     if (!c) return;
     DevGuard g(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->d_img, c->d_pyr, c->d_zero, c->d_list, c->d_listcount, c->d_pre, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_gradp,
+    void *ptrs[] = {c->d_img, c->d_pyr, c->d_zero, c->d_list, c->d_listcount, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_gradp,
                     c->d_gradfull, c->d_kps, c->d_desc, c->d_total, c->d_ori, c->d_tab, c->d_qtab};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &ps : c->prof)
