@@ -43,20 +43,24 @@ __device__ __forceinline__ uint32_t gradp_pack(int ang, int mag)
     return ang ? ((uint32_t)mag | ((uint32_t)(ang - 1) << 9)) : 0u;
 }
 
-// ComputeGradientKernel (:1186-1225).  mag = floor(sqrt(s)), s = gx^2+gy^2 <= 130050: with s exact
-// in binary32, floor(sqrt(s + 0.5)) equals the integer square root even with a 1-ulp sqrt (the
-// distance of sqrt(s + 0.5) to the nearest integer is >= 0.25/361).
+// ComputeGradientKernel (:1186-1225), branch-free.
+//   mag = floor(sqrt(s)), s = gx^2+gy^2 <= 130050: with s exact in binary32,
+//   floor(sqrt(s + 0.5)) equals the integer square root even with a 1-ulp sqrt (the distance of
+//   sqrt(s + 0.5) to the nearest integer is >= 0.25/361).
+//   code (:1206-1213): 0 if gx*gy == 0; otherwise with sy = [gy<0], x = [gx*gy<0] the quadrant
+//   pair is 2*(2 sy + x) + 1 and the second code of the pair is taken unless |gx| > |gy| (pairs
+//   1/2, 5/6: x = 0) resp. |gx| < |gy| (pairs 3/4, 7/8: x = 1).
 __device__ __forceinline__ void grad_code(int gx, int gy, int &ang, int &mag)
 {
-    const int s = gx * gx + gy * gy;
-    mag = (int)__builtin_amdgcn_sqrtf((float)s + 0.5f);   // v_sqrt_f32
-    const int ax = gx < 0 ? -gx : gx, ay = gy < 0 ? -gy : gy;
-    int a = 0;
-    if (gx > 0 && gy > 0) a = ax > ay ? 1 : 2;
-    else if (gx < 0 && gy > 0) a = ax < ay ? 3 : 4;
-    else if (gx < 0 && gy < 0) a = ax > ay ? 5 : 6;
-    else if (gx > 0 && gy < 0) a = ax < ay ? 7 : 8;
-    ang = a;
+    const int gx2 = gx * gx, gy2 = gy * gy;
+    mag = (int)__builtin_amdgcn_sqrtf((float)(gx2 + gy2) + 0.5f);      // v_sqrt_f32
+    const int p = gx * gy;
+    const int xm = p >> 31;                                            // -1 where gx, gy differ in sign
+    const int dd = ((gx2 - gy2) ^ xm) - xm;                            // |gx|-|gy| signed so that "first code" is dd > 0
+    const uint32_t t = (uint32_t)(dd - 1) >> 31;                       // 1 unless dd > 0
+    const uint32_t sy = (uint32_t)gy >> 31;
+    const int a = (int)((sy << 2) + ((uint32_t)xm & 2u) + 1u + t);
+    ang = p ? a : 0;
 }
 
 __device__ __forceinline__ int byte_of(uint32_t w, int p) { return (int)((w >> (8 * p)) & 0xffu); }
