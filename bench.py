@@ -138,13 +138,24 @@ def main():
                        "parallelism": "frames x%d" % a.gpus, "resident": "inputs and outputs in HBM"},
         }
         if stage is not None:
+            kp_mean = float(np.minimum(totals, K).mean())
+            # algorithmic bytes per launch (SURVEY.md 8(d) per-frame figures x B frames)
+            alg = {
+                "k_blur": 5.0 * W * H * B,                       # read u8 image, write {src,G1,G2,G3}: 5 B per pixel
+                "k_detect": 6.0 * W * H * B,                     # read the 4 B/pixel planes, write 2 B/pixel gradients
+                "k_describe": (min(20164.0 * kp_mean, 4.0 * W * H) + 2880000.0 + 80000.0) * B,
+            }
+            dom = max(alg, key=lambda k: stage[k])               # the kernel that takes the most time
+            wl = "%dx%dx%d" % (W, H, B)
+
+            def roof(k):
+                ach = alg[k] / (stage[k] * 1e-3) / 1e9
+                return {"kernel": k, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": load_traffic(k, wl),
+                        "algorithmic_bytes_per_launch": alg[k], "avg_launch_ms": stage[k]}
+            out["roofline"] = roof(dom)
+            out["roofline_other"] = [roof(k) for k in alg if k != dom]
             t_blur = stage["k_blur"] * 1e-3
-            alg_bytes = 5.0 * W * H * B        # read u8 image, write src|G1|G2|G3 word: 5 B per pixel
-            ach = alg_bytes / t_blur / 1e9
-            out["roofline"] = {"kernel": "k_blur", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": load_traffic("k_blur", "%dx%dx%d" % (W, H, B)),
-                               "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": stage["k_blur"]}
             macs = 507.0 * W * H * B
             out["valu"] = {"kernel": "k_blur", "achieved": macs / t_blur / 1e12, "peak": DOT4_PEAK_TMACS,
                            "unit": "TMAC/s (u8 dot4)", "frac": macs / t_blur / 1e12 / DOT4_PEAK_TMACS}
