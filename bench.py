@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--contrast-th", type=int, default=15)
@@ -75,12 +75,18 @@ def main():
     import sift_amd
     from sift_amd.shard import DistEnv, frame_seeds
 
-    env = DistEnv()
+    # SIFT_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N>1 path on a
+    # one-GPU box; RCCL refuses two ranks on one device).  The driver's runs use RCCL ("nccl").
+    env = DistEnv(backend=os.environ.get("SIFT_BENCH_BACKEND") or None)
     if env.world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (a.gpus, env.world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a gfx950 GPU: there is no CPU fallback")
     dev = env.local_rank
+    if dev >= torch.cuda.device_count():
+        if env.backend != "gloo":
+            raise SystemExit("rank %d has no GPU (%d visible)" % (env.rank, torch.cuda.device_count()))
+        dev %= torch.cuda.device_count()
     torch.cuda.set_device(dev)
     W, H, B, K = a.width, a.height, a.batch, sift_amd.MAX_KEYPOINTS
 
