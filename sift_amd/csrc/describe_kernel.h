@@ -23,9 +23,9 @@
 //
 // Lanes l and l+32 accumulate into LDS column l of hist[row][32] (bank =
 // column: no conflicts inside a half wave; ds_add_u32 without return).
-//   * internal gradient format (k_detect's 2-byte plane): one word is
-//     mag | a << 9 with a = code-1, and 0 for code 0, so every pixel is added
-//     without a test (code 0 is accumulated and then discarded by the
+//   * internal gradient format (k_detect's 2-byte plane, gradp_pack): one word
+//     is mag | (a>>1) << 9 | (a&1) << 15 with a = code-1, and 0 for code 0, so
+//     every pixel is added without a test (code 0 is accumulated and then discarded by the
 //     reference, :245-252).  Two direction bins share a dword as 16-bit
 //     halves: row = circle*4 + (a>>1), half = a&1 (40 rows, 5 KB per wave).
 //     A half holds at most 2 lanes x 61 pixels x 360 < 2^16.
@@ -147,9 +147,9 @@ __global__ __launch_bounds__(64) void k_describe(const void *__restrict__ gradv,
     };
     auto accumulate = [&](auto two, uint32_t hi, uint32_t g) {
         if constexpr (PACK) {
-            // g = mag | a << 9 (0 for code 0): value into half a&1 of row circle*4 + (a>>1)
-            const uint32_t v = (g & 0x1ffu) << ((g >> 5) & 16u);
-            const uint32_t rl = ((g >> 10) << 7) | col4;               // (a>>1) * 128 + column
+            // g = gradp word (0 for code 0): value into half a&1 of row circle*4 + (a>>1)
+            const uint32_t v = (g & 0x1ffu) << (g >> 11);
+            const uint32_t rl = (((g >> 9) & 3u) << 7) | col4;         // (a>>1) * 128 + column
             add((hi & 0x1e00u) | rl, v);                               // circle * 512
             if constexpr (decltype(two)::value) {
                 add(((hi >> 16) & 0x1e00u) | rl, v);
@@ -195,10 +195,10 @@ __global__ __launch_bounds__(64) void k_describe(const void *__restrict__ gradv,
     };
     // quad sweep (internal format, window inside the plane)
     auto quad_pixel = [&](auto two, uint32_t g, uint32_t cc, uint32_t ovsel) {
-        // g = mag | a << 9; cc = c1 | c2 << 4 in its low byte; ovsel bit 10 set = not an overlap
+        // g = gradp word; cc = c1 | c2 << 4 in its low byte; ovsel bit 10 set = not an overlap
         // pixel: circle id 9 | 2 = 11, a spare row like id 10
-        const uint32_t v = (g & 0x1ffu) << ((g >> 5) & 16u);
-        const uint32_t rl = ((g >> 10) << 7) | col4;
+        const uint32_t v = (g & 0x1ffu) << (g >> 11);
+        const uint32_t rl = (((g >> 9) & 3u) << 7) | col4;
         add(((cc & 15u) << 9) | rl, v);
         if constexpr (decltype(two)::value) {
             add((((cc >> 4) & 15u) << 9) | rl, v);

@@ -25,7 +25,7 @@
 //   candmask[y][seg]  u64, bit = pre-cull candidate (raster order; every word of the strip written)
 //   keyplane[y][x]    u32, written ONLY at candidates: (E_q15 << 8) | |D2|
 //   list[]            the candidates as (y << 16 | x), appended per strip (order irrelevant)
-//   gradp[y][x]       u16 mag | (code-1) << 9, 0 for code 0   (internal, 2 B/pixel)
+//   gradp[y][x]       u16 gradp_pack(code, mag)                (internal, 2 B/pixel)
 //   gradfull[y][x]    Grad_t {ang, mag}                        (optional, sift_detect API)
 // and it zeroes survmask / rowcount, which k_cull fills with atomics.
 #pragma once
@@ -36,11 +36,14 @@ namespace sift {
 
 typedef unsigned long long u64;
 
-// internal 2-byte gradient word (written by k_detect, read by k_describe): mag | (code-1) << 9,
-// and 0 for code 0, whose magnitude never reaches a descriptor bin
+// internal 2-byte gradient word (written by k_detect, read by k_describe), a = code - 1:
+//   bits 0-8 mag, bits 9-10 a >> 1, bits 11-14 zero, bit 15 a & 1     (0 for code 0, whose
+// magnitude never reaches a descriptor bin).  word >> 11 is then the shift (0 or 16) that puts
+// the magnitude into the 16-bit half of its LDS bin pair.
 __device__ __forceinline__ uint32_t gradp_pack(int ang, int mag)
 {
-    return ang ? ((uint32_t)mag | ((uint32_t)(ang - 1) << 9)) : 0u;
+    const uint32_t a = (uint32_t)(ang - 1);
+    return ang ? ((uint32_t)mag | ((a >> 1) << 9) | ((a & 1u) << 15)) : 0u;
 }
 
 // ComputeGradientKernel (:1186-1225), branch-free.
