@@ -597,35 +597,73 @@ int sift_hip_batch(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *im
             return fail(SIFT_HIP_EINVAL, "contexts differ in frame size or max_keypoints");
     }
     for (int f = 0; f < nframes; f++) if (!imgs[f]) return fail(SIFT_HIP_EINVAL, "null frame");
-    // one host thread per context (= per GPU); context i takes frames i, i+nctx, ...
-    // in chunks of its max_batch.  No exchange between contexts.
+    // one host thread per context (= per GPU); context i takes frames i, i+nctx, ...  No exchange
+    // between contexts.  Inside a context the frames go through in chunks of half its max_batch,
+    // double buffered: the H2D copy of chunk k+1 and the D2H copy of chunk k-1 run on their own
+    // streams beside the kernels of chunk k (the overlapped ingest of main.cpp:41-58 / :82-184).
     std::vector<int> rc(nctx, SIFT_HIP_OK);
     std::vector<std::string> msg(nctx);
     auto worker = [&](int ci) {
         sift_hip_ctx *c = ctxs[ci];
         DevGuard g(c->device);
-        hipStream_t s = c->stream;
         const size_t np = c->npix, K = (size_t)c->max_kp;
         std::vector<int> mine;
         for (int f = ci; f < nframes; f += nctx) mine.push_back(f);
-        for (size_t b0 = 0; b0 < mine.size() && rc[ci] == SIFT_HIP_OK; b0 += (size_t)c->max_batch) {
-            const int nb = (int)std::min((size_t)c->max_batch, mine.size() - b0);
-            auto step = [&](hipError_t e, const char *what) {
-                if (e != hipSuccess && rc[ci] == SIFT_HIP_OK) { rc[ci] = SIFT_HIP_EHIP; msg[ci] = std::string(what) + ": " + hipGetErrorString(e); }
-            };
+        if (mine.empty()) return;
+        auto step = [&](hipError_t e, const char *what) {
+            if (e != hipSuccess && rc[ci] == SIFT_HIP_OK) { rc[ci] = SIFT_HIP_EHIP; msg[ci] = std::string(what) + ": " + hipGetErrorString(e); }
+        };
+        const int half = c->max_batch >= 2 ? c->max_batch / 2 : c->max_batch;   // frames per chunk
+        const int nbuf = c->max_batch >= 2 ? 2 : 1;
+        hipStream_t s_in = nullptr, s_out = nullptr, s = c->stream;
+        hipEvent_t in_done[2] = {}, k_done[2] = {}, out_done[2] = {};
+        step(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking), "stream");
+        step(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking), "stream");
+        for (int i = 0; i < 2; i++) {
+            step(hipEventCreateWithFlags(&in_done[i], hipEventDisableTiming), "event");
+            step(hipEventCreateWithFlags(&k_done[i], hipEventDisableTiming), "event");
+            step(hipEventCreateWithFlags(&out_done[i], hipEventDisableTiming), "event");
+        }
+        size_t chunk = 0;
+        for (size_t b0 = 0; b0 < mine.size() && rc[ci] == SIFT_HIP_OK; b0 += (size_t)half, chunk++) {
+            const int nb = (int)std::min((size_t)half, mine.size() - b0);
+            const int h = (int)(chunk % (size_t)nbuf);
+            uint8_t *d_img = c->d_img + (size_t)h * half * np;
+            sift::kp_t *d_kps = c->d_kps + (size_t)h * half * K;
+            uint32_t *d_desc = c->d_desc + (size_t)h * half * K * 72;
+            // H2D into buffer h once the kernels that last read it (chunk - nbuf) are done
+            if (chunk >= (size_t)nbuf) step(hipStreamWaitEvent(s_in, k_done[h], 0), "wait");
             for (int k = 0; k < nb; k++)
-                step(hipMemcpyAsync(c->d_img + (size_t)k * np, imgs[mine[b0 + k]], np, hipMemcpyHostToDevice, s), "H2D frame");
+                step(hipMemcpyAsync(d_img + (size_t)k * np, imgs[mine[b0 + k]], np, hipMemcpyHostToDevice, s_in), "H2D frame");
+            step(hipEventRecord(in_done[h], s_in), "record");
+            // kernels: after the frames have arrived and the previous outputs of buffer h have left
+            step(hipStreamWaitEvent(s, in_done[h], 0), "wait");
+            if (chunk >= (size_t)nbuf) step(hipStreamWaitEvent(s, out_done[h], 0), "wait");
             if (rc[ci] == SIFT_HIP_OK) {
-                int r = sift_hip_detect_and_compute_dev(c, c->d_img, nb, (sift_keypoint *)c->d_kps, c->d_desc, c->d_total, contrastTh, s);
+                int r = sift_hip_detect_and_compute_dev(c, d_img, nb, (sift_keypoint *)d_kps, d_desc, c->d_total + (size_t)h * half,
+                                                        contrastTh, s);
                 if (r) { rc[ci] = r; msg[ci] = g_err; }
             }
+            step(hipEventRecord(k_done[h], s), "record");
+            // D2H
+            step(hipStreamWaitEvent(s_out, k_done[h], 0), "wait");
             for (int k = 0; k < nb && rc[ci] == SIFT_HIP_OK; k++) {
                 const size_t f = (size_t)mine[b0 + k];
-                step(hipMemcpyAsync(kps + f * K, c->d_kps + (size_t)k * K, K * 8, hipMemcpyDeviceToHost, s), "D2H keypoints");
-                step(hipMemcpyAsync(desc + f * K * 72, c->d_desc + (size_t)k * K * 72, K * 72 * 4, hipMemcpyDeviceToHost, s), "D2H descriptors");
+                step(hipMemcpyAsync(kps + f * K, d_kps + (size_t)k * K, K * 8, hipMemcpyDeviceToHost, s_out), "D2H keypoints");
+                step(hipMemcpyAsync(desc + f * K * 72, d_desc + (size_t)k * K * 72, K * 72 * 4, hipMemcpyDeviceToHost, s_out), "D2H descriptors");
             }
-            step(hipStreamSynchronize(s), "sync");
+            step(hipEventRecord(out_done[h], s_out), "record");
         }
+        if (s_in) step(hipStreamSynchronize(s_in), "sync");
+        step(hipStreamSynchronize(s), "sync");
+        if (s_out) step(hipStreamSynchronize(s_out), "sync");
+        for (int i = 0; i < 2; i++) {
+            if (in_done[i]) (void)hipEventDestroy(in_done[i]);
+            if (k_done[i]) (void)hipEventDestroy(k_done[i]);
+            if (out_done[i]) (void)hipEventDestroy(out_done[i]);
+        }
+        if (s_in) (void)hipStreamDestroy(s_in);
+        if (s_out) (void)hipStreamDestroy(s_out);
     };
     if (nctx == 1) {
         worker(0);
