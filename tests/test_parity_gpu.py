@@ -94,6 +94,24 @@ def test_ragged_and_tiny_sizes(sift, orc, W, H):
     check_full(sift, orc, img)
 
 
+@pytest.mark.parametrize("case", range(12))
+def test_random_frames_random_sizes(sift, orc, case):
+    """seeded random content (smooth blobs + noise + steps) at random sizes, every stage compared"""
+    rng = np.random.default_rng(1000 + case)
+    W = int(rng.integers(37, 130)) * 4
+    H = int(rng.integers(145, 420))
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.zeros((H, W), np.float64)
+    for _ in range(int(rng.integers(20, 200))):
+        cx, cy, r = rng.uniform(0, W), rng.uniform(0, H), rng.uniform(1.5, 12)
+        img += rng.uniform(-120, 120) * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * r * r))
+    img += rng.normal(0, rng.uniform(0, 6), img.shape)
+    if case % 3 == 0:
+        img[:, W // 2:] += 90                                       # a step edge: edge-ratio rejections
+    img = np.clip(img + 128, 0, 255).astype(np.uint8)
+    check_full(sift, orc, img, th=int(rng.integers(1, 25)))
+
+
 @pytest.mark.parametrize("fill", [0, 255, 37])
 def test_flat_frames(sift, orc, fill):
     check_full(sift, orc, np.full((176, 192), fill, np.uint8))
