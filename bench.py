@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--contrast-th", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the keypoint-count sanity check (kernel experiments)")
     ap.add_argument("--no-profile-events", action="store_true", help="leave the per-kernel HIP events out")
     a = ap.parse_args()
 
@@ -121,7 +122,8 @@ def main():
 
     # sanity (parity proper lives in tests/): the seed-1 frame must give the oracle's keypoint count
     totals = d_tot.cpu().numpy()
-    if env.rank == 0 and (W, H, a.contrast_th) == (1920, 1080, 15) and int(totals[0]) != EXPECTED_KP_1080P_SEED1:
+    if (env.rank == 0 and not a.no_check and (W, H, a.contrast_th) == (1920, 1080, 15)
+            and int(totals[0]) != EXPECTED_KP_1080P_SEED1):
         raise SystemExit("wrong result: %d keypoints on the seed-1 frame, expected %d"
                          % (int(totals[0]), EXPECTED_KP_1080P_SEED1))
 
