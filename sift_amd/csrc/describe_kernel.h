@@ -81,12 +81,13 @@ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)   // v_pk_add
 }
 
 // grid: x = max_kp keypoints, y = frames; block = 64 (one wave)
-template <int GFMT, int MODE>
+template <int GFMT, int MODE, bool LOOP = false>
 __global__ __launch_bounds__(64) void k_describe(const void *__restrict__ gradv, const kp_t *__restrict__ kps,
                                                  const uint8_t *__restrict__ ori_in, uint8_t *__restrict__ ori_out,
                                                  uint32_t *__restrict__ desc, const uint2 *__restrict__ tab,
                                                  int n2, int n2pad, int ntab, const uint2 *__restrict__ qtab,
-                                                 int qa, int qb, int W, int H, int max_kp)
+                                                 int qa, int qb, const uint32_t *__restrict__ total, int W, int H,
+                                                 int max_kp)
 {
     constexpr bool PACK = GFMT == GRAD_PACKED16;
     constexpr int ROWS = PACK ? 40 : 80;         // rows that hold bins
@@ -96,7 +97,17 @@ __global__ __launch_bounds__(64) void k_describe(const void *__restrict__ gradv,
     __shared__ uint32_t fin[80];
 
     const int lane = threadIdx.x;
-    const size_t slot = (size_t)blockIdx.y * max_kp + blockIdx.x;
+    // slots blockIdx.x, + gridDim.x, ...; in the fused mode `total` (k_emit's count) tells which
+    // slots are padding without reading them
+    const int nfilled = total ? (int)min(total[blockIdx.y], (uint32_t)max_kp) : max_kp;
+    // LOOP = false: the grid has one workgroup per slot
+    for (int kslot = blockIdx.x; kslot < max_kp; kslot += LOOP ? (int)gridDim.x : max_kp) {
+    const size_t slot = (size_t)blockIdx.y * max_kp + kslot;
+    if (kslot >= nfilled) {                          // padding slot: descriptor defined as 0
+        desc[slot * 72 + lane] = 0;
+        if (lane < 8) desc[slot * 72 + 64 + lane] = 0;
+        continue;
+    }
     const kp_t kp = kps[slot];
     const int px = kp.x, py = kp.y;
     uint32_t *__restrict__ out = desc ? desc + slot * 72 : nullptr;
@@ -107,7 +118,7 @@ __global__ __launch_bounds__(64) void k_describe(const void *__restrict__ gradv,
             if (lane < 8) out[64 + lane] = 0;
         }
         if (MODE != DESC_GIVEN_ORI && ori_out && lane == 0) ori_out[slot] = 0;
-        return;
+        continue;
     }
 
     {
@@ -287,13 +298,13 @@ __global__ __launch_bounds__(64) void k_describe(const void *__restrict__ gradv,
         m = key ? 8u - (key & 7u) : 0u;
         if (ori_out && lane == 0) ori_out[slot] = (uint8_t)m;
     }
-    if (MODE == DESC_ORI_ONLY) return;
-
     // rotation (:346-393): out[c][j] = Hin[c<8 ? (c+m)&7 : 8][(j+m)&7]
-    {
+    if (MODE != DESC_ORI_ONLY) {
         const int c = lane >> 3, j = lane & 7;       // circles 0..7
         out[lane] = fin[((c + m) & 7) * 8 + ((j + m) & 7)];
         if (lane < 8) out[64 + lane] = fin[64 + ((lane + m) & 7)];
+    }
+    if (LOOP) __syncthreads();                       // hist and fin are reused by the next slot
     }
 }
 

@@ -175,7 +175,8 @@ struct sift_hip_ctx {
     uint32_t *d_gradfull = nullptr;       // Grad_t staging (1 frame, lazily allocated)
     sift::kp_t *d_kps = nullptr;          // staging for host-buffer entry points
     uint32_t *d_desc = nullptr;
-    uint32_t *d_total = nullptr;
+    uint32_t *d_total = nullptr;          // staging for host-buffer entry points
+    uint32_t *d_total_ctx = nullptr;      // k_emit's uncapped count per frame, read by the fused describe kernel
     uint8_t *d_ori = nullptr;
     uint2 *d_tab = nullptr, *d_qtab = nullptr;
     int ntab = 0, n2 = 0, n2pad = 0, qa = 0, qb = 0;
@@ -230,8 +231,9 @@ int pick_blur_rows(const sift_hip_ctx *c, int nframes)
 }
 
 // blur -> detect -> cull -> emit on device-resident frames
+// d_desc_pad: descriptor array whose padding slots k_emit zeroes (NULL: none)
 int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_gradfull, sift::kp_t *d_kps,
-               uint32_t *d_total, int th, hipStream_t s)
+               uint32_t *d_total, uint32_t *d_desc_pad, int th, hipStream_t s)
 {
     const int W = c->W, H = c->H, S = c->S;
     c->last_frames = nframes;
@@ -268,8 +270,8 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
     {
         StageTimer t(c, ST_EMIT, s);
         dim3 grid((H + 1 + 3) / 4, nframes);
-        hipLaunchKernelGGL(sift::k_emit, grid, dim3(256), 0, s, c->d_surv, c->d_key, c->d_rowcount, d_kps, d_total,
-                           W, H, S, c->max_kp);
+        hipLaunchKernelGGL(sift::k_emit, grid, dim3(256), 0, s, c->d_surv, c->d_key, c->d_rowcount, d_kps,
+                           c->d_total_ctx, d_total, d_desc_pad, W, H, S, c->max_kp);
     }
     HIP_TRY(hipGetLastError());
     return SIFT_HIP_OK;
@@ -280,9 +282,18 @@ int run_describe(sift_hip_ctx *c, const void *d_grad, int nframes, const sift::k
                  uint8_t *ori_out, uint32_t *d_desc, hipStream_t s)
 {
     StageTimer t(c, ST_DESCRIBE, s);
-    dim3 grid(c->max_kp, nframes);
-    hipLaunchKernelGGL((sift::k_describe<GFMT, MODE>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out, d_desc,
-                       c->d_tab, c->n2, c->n2pad, c->ntab, c->d_qtab, c->qa, c->qb, c->W, c->H, c->max_kp);
+    // one wave per slot, or per group of slots when the batch is so large that the launch would
+    // exceed ~650k waves (sparse frames: most of them would only write zeros)
+    const bool fused = MODE == sift::DESC_FUSED;
+    const int gx = std::max(1024, std::min(c->max_kp, (655360 + nframes - 1) / nframes));
+    dim3 grid(std::min(gx, c->max_kp), nframes);
+    const uint32_t *tot = fused ? (const uint32_t *)c->d_total_ctx : (const uint32_t *)nullptr;
+    if ((int)grid.x == c->max_kp)
+        hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->d_qtab, c->qa, c->qb, tot, c->W, c->H, c->max_kp);
+    else
+        hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->d_qtab, c->qa, c->qb, tot, c->W, c->H, c->max_kp);
     HIP_TRY(hipGetLastError());
     return SIFT_HIP_OK;
 }
@@ -379,6 +390,7 @@ int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int m
     A((void **)&c->d_kps, B * (size_t)max_keypoints * 8);
     A((void **)&c->d_desc, B * (size_t)max_keypoints * 72 * 4);
     A((void **)&c->d_total, B * 4);
+    A((void **)&c->d_total_ctx, B * 4);
     A((void **)&c->d_ori, B * (size_t)max_keypoints);
     A((void **)&c->d_tab, tab.size() * sizeof(uint2));
     c->ntab = (int)tab.size(); c->n2 = wt.n2; c->n2pad = wt.n2pad;
@@ -400,7 +412,7 @@ void sift_hip_destroy(sift_hip_ctx *c)
     DevGuard g(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_img, c->d_pyr, c->d_zero, c->d_list, c->d_listcount, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_gradp,
-                    c->d_gradfull, c->d_kps, c->d_desc, c->d_total, c->d_ori, c->d_tab, c->d_qtab};
+                    c->d_gradfull, c->d_kps, c->d_desc, c->d_total, c->d_total_ctx, c->d_ori, c->d_tab, c->d_qtab};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &ps : c->prof)
         for (int i = 0; i < SIFT_HIP_NSTAGES; i++)
@@ -473,7 +485,7 @@ int sift_hip_detect_dev(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, sif
     DevGuard g(c->device);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     begin_call(c);
-    return run_detect(c, d_imgs, nframes, (uint32_t *)d_grad, (sift::kp_t *)d_kps, d_total, contrastTh, s);
+    return run_detect(c, d_imgs, nframes, (uint32_t *)d_grad, (sift::kp_t *)d_kps, d_total, nullptr, contrastTh, s);
 }
 
 int sift_hip_detect_and_compute_dev(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, sift_keypoint *d_kps,
@@ -485,7 +497,7 @@ int sift_hip_detect_and_compute_dev(sift_hip_ctx *c, const uint8_t *d_imgs, int 
     DevGuard g(c->device);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     begin_call(c);
-    if (int r = run_detect(c, d_imgs, nframes, nullptr, (sift::kp_t *)d_kps, d_total, contrastTh, s)) return r;
+    if (int r = run_detect(c, d_imgs, nframes, nullptr, (sift::kp_t *)d_kps, d_total, nullptr, contrastTh, s)) return r;
     return run_describe<sift::GRAD_PACKED16, sift::DESC_FUSED>(c, c->d_gradp, nframes, (const sift::kp_t *)d_kps,
                                                                nullptr, nullptr, d_desc, s);
 }
