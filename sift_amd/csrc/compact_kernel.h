@@ -90,13 +90,13 @@ __global__ __launch_bounds__(256) void k_cull(const u64 *__restrict__ candmask, 
 
 // One wave per image row (+ one extra wave per frame for padding / totals: total_ctx is the
 // context's own copy of the uncapped count, which the fused describe kernel reads; total_out the
-// caller's, optional; `desc`, optional, gets zeros in the padding slots).
+// caller's, optional).
 // grid: x = ceil((H+1)/4) blocks of 256, y = frames.
 __global__ __launch_bounds__(256) void k_emit(const u64 *__restrict__ survmask,
                                               const uint32_t *__restrict__ keyplane,
                                               const uint32_t *__restrict__ rowcount, kp_t *__restrict__ kps,
                                               uint32_t *__restrict__ total_ctx, uint32_t *__restrict__ total_out,
-                                              uint32_t *__restrict__ desc, int W, int H, int S, int max_kp)
+                                              int W, int H, int S, int max_kp)
 {
     const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (y > H) return;
@@ -121,11 +121,6 @@ __global__ __launch_bounds__(256) void k_emit(const u64 *__restrict__ survmask,
         const uint32_t first = base < (uint32_t)max_kp ? base : (uint32_t)max_kp;
         u64 *o64 = reinterpret_cast<u64 *>(out);
         for (uint32_t i = first + lane; i < (uint32_t)max_kp; i += 64) o64[i] = 0ull;
-        // descriptors of the padding slots: 0 (SIFT_Descriptor.cpp:194-196 leaves them uninitialised)
-        if (desc) {
-            uint4 *d4 = reinterpret_cast<uint4 *>(desc + (size_t)blockIdx.y * max_kp * 72);   // 18 uint4 per slot
-            for (size_t i = (size_t)first * 18 + lane; i < (size_t)max_kp * 18; i += 64) d4[i] = make_uint4(0, 0, 0, 0);
-        }
         return;
     }
     if (base >= (uint32_t)max_kp) return;            // cap reached above this row (:409)

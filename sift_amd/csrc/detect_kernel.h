@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
             const int mn = min(min(min(Fl, F[p]), Fr), min(min(BIl, BIr), min(st[p].b0, b2[p])));
             const int ac = c < 0 ? -c : c;
             // strict 26-neighbour extremum (:245-304), |D2| >= contrastTh (:194), kpOut = |c| non-zero (:684)
-            pre[p] = colvalid && ((c > mx) || (c < mn)) && ac >= contrastTh && ac > 0;
+            pre[p] = colvalid & ((c > mx) | (c < mn)) & (ac >= contrastTh) & (ac > 0);
             nib |= pre[p] ? (1u << p) : 0u;
         }
 

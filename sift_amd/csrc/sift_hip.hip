@@ -171,7 +171,7 @@ struct sift_hip_ctx {
     int list_cap = 0;
     uint32_t *d_key = nullptr;            // (E<<8)|contrast at candidates
     uint32_t *d_rowcount = nullptr;       // [H]
-    uint16_t *d_gradp = nullptr;          // (ang<<12)|mag
+    uint16_t *d_gradp = nullptr;          // internal gradient plane (gradp_pack, detect_kernel.h)
     uint32_t *d_gradfull = nullptr;       // Grad_t staging (1 frame, lazily allocated)
     sift::kp_t *d_kps = nullptr;          // staging for host-buffer entry points
     uint32_t *d_desc = nullptr;
@@ -231,9 +231,8 @@ int pick_blur_rows(const sift_hip_ctx *c, int nframes)
 }
 
 // blur -> detect -> cull -> emit on device-resident frames
-// d_desc_pad: descriptor array whose padding slots k_emit zeroes (NULL: none)
 int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_gradfull, sift::kp_t *d_kps,
-               uint32_t *d_total, uint32_t *d_desc_pad, int th, hipStream_t s)
+               uint32_t *d_total, int th, hipStream_t s)
 {
     const int W = c->W, H = c->H, S = c->S;
     c->last_frames = nframes;
@@ -271,7 +270,7 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
         StageTimer t(c, ST_EMIT, s);
         dim3 grid((H + 1 + 3) / 4, nframes);
         hipLaunchKernelGGL(sift::k_emit, grid, dim3(256), 0, s, c->d_surv, c->d_key, c->d_rowcount, d_kps,
-                           c->d_total_ctx, d_total, d_desc_pad, W, H, S, c->max_kp);
+                           c->d_total_ctx, d_total, W, H, S, c->max_kp);
     }
     HIP_TRY(hipGetLastError());
     return SIFT_HIP_OK;
@@ -485,7 +484,7 @@ int sift_hip_detect_dev(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, sif
     DevGuard g(c->device);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     begin_call(c);
-    return run_detect(c, d_imgs, nframes, (uint32_t *)d_grad, (sift::kp_t *)d_kps, d_total, nullptr, contrastTh, s);
+    return run_detect(c, d_imgs, nframes, (uint32_t *)d_grad, (sift::kp_t *)d_kps, d_total, contrastTh, s);
 }
 
 int sift_hip_detect_and_compute_dev(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, sift_keypoint *d_kps,
@@ -497,7 +496,7 @@ int sift_hip_detect_and_compute_dev(sift_hip_ctx *c, const uint8_t *d_imgs, int 
     DevGuard g(c->device);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     begin_call(c);
-    if (int r = run_detect(c, d_imgs, nframes, nullptr, (sift::kp_t *)d_kps, d_total, nullptr, contrastTh, s)) return r;
+    if (int r = run_detect(c, d_imgs, nframes, nullptr, (sift::kp_t *)d_kps, d_total, contrastTh, s)) return r;
     return run_describe<sift::GRAD_PACKED16, sift::DESC_FUSED>(c, c->d_gradp, nframes, (const sift::kp_t *)d_kps,
                                                                nullptr, nullptr, d_desc, s);
 }
