@@ -81,8 +81,10 @@ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)   // v_pk_add
 }
 
 // grid: x = max_kp keypoints, y = frames; block = 64 (one wave)
-template <int GFMT, int MODE, bool LOOP = false>
-__global__ __launch_bounds__(64) void k_describe(const void *__restrict__ gradv, const kp_t *__restrict__ kps,
+// NA, NB > 0: the quad table has exactly NA and NB steps of 64 quads (the reference's masks: 5 and
+// 11) and the sweep is straight-line code with every load of the window in flight at once
+template <int GFMT, int MODE, bool LOOP = false, int NA = 0, int NB = 0>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_describe(const void *__restrict__ gradv, const kp_t *__restrict__ kps,
                                                  const uint8_t *__restrict__ ori_in, uint8_t *__restrict__ ori_out,
                                                  uint32_t *__restrict__ desc, const uint2 *__restrict__ tab,
                                                  int n2, int n2pad, int ntab, const uint2 *__restrict__ qtab,
@@ -232,6 +234,25 @@ __global__ __launch_bounds__(64) void k_describe(const void *__restrict__ gradv,
             quad_pixel(two, q[u].y >> 16, e[u].y >> 24, e[u].x >> 17);
         }
     };
+    // A wave's time is mostly load latency (table entry -> quad -> adds), so the static variant
+    // issues all NA + NB table loads, then all gathers, and only then starts adding.
+    auto quad_static = [&](const char *gq, const char *tq) {
+        constexpr int N = NA + NB > 0 ? NA + NB : 1;
+        uint2 e[N], q[N];
+        const uint32_t tb = (uint32_t)lane * 8u;
+#pragma unroll
+        for (int u = 0; u < N; u++) e[u] = *reinterpret_cast<const uint2 *>(tq + tb + (uint32_t)u * 512u);
+#pragma unroll
+        for (int u = 0; u < N; u++) q[u] = *reinterpret_cast<const uint2 *>(gq + (e[u].x & 0xffffffu));
+        static_for<0, N>([&](auto uu) {
+            constexpr int u = uu;
+            std::integral_constant<bool, (u < NA)> two;
+            quad_pixel(two, q[u].x & 0xffffu, e[u].y, e[u].x >> 14);
+            quad_pixel(two, q[u].x >> 16, e[u].y >> 8, e[u].x >> 15);
+            quad_pixel(two, q[u].y & 0xffffu, e[u].y >> 16, e[u].x >> 16);
+            quad_pixel(two, q[u].y >> 16, e[u].y >> 24, e[u].x >> 17);
+        });
+    };
     auto quad_part = [&](auto two, const char *gq, const char *tq, int begin, int end) {
         int t0 = begin;
         for (; t0 + 64 * U <= end; t0 += 64 * U) quad_chunk(two, std::integral_constant<int, U>{}, gq, tq, t0);
@@ -244,8 +265,12 @@ __global__ __launch_bounds__(64) void k_describe(const void *__restrict__ gradv,
         const int phase = (px - 35) & 3;             // = origin & 3 because W % 4 == 0
         const char *gq = gplane + (origin - phase) * 2;
         const char *tq = reinterpret_cast<const char *>(qtab + (size_t)phase * (size_t)(qa + qb));
-        quad_part(std::true_type{}, gq, tq, 0, qa);
-        quad_part(std::false_type{}, gq, tq, qa, qa + qb);
+        if constexpr (NA + NB > 0) {
+            quad_static(gq, tq);
+        } else {
+            quad_part(std::true_type{}, gq, tq, 0, qa);
+            quad_part(std::false_type{}, gq, tq, qa, qa + qb);
+        }
     } else if (inside) {
         sweep(std::false_type{});
     } else {

@@ -1,0 +1,95 @@
+// TA cost of window gathers on gfx950: each wave reads a 71-row window of a 2-byte plane either as
+// 8-byte quads (19 per row) or as 16-byte chunks (10 per row), lanes = consecutive pieces, rows W*2
+// bytes apart; windows at random aligned positions.  Prints ns per wave-instruction per CU.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <vector>
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+// NEAR > 0: the waves of a block read windows within NEAR pixels of the block's origin (spatial neighbours)
+template <int BYTES, int NEAR = 0>
+__global__ void k(const char *plane, const uint32_t *origins, uint32_t *out, int W, int iters)
+{
+    constexpr int PER_ROW = BYTES == 8 ? 19 : 10;
+    constexpr int N = 71 * PER_ROW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; it++) {
+        const char *base = plane + origins[(blockIdx.x * iters + it) & 0xffff];
+        if (NEAR) base += ((wave * 5) % NEAR) * W * 2 + ((wave * 12) % NEAR) * 2 / 8 * 8;
+        for (int i0 = 0; i0 < N; i0 += 256) {
+            uint32_t v[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                int i = i0 + u * 64 + lane;
+                i = i < N ? i : N - 1;
+                const int r = i / PER_ROW, q = i - r * PER_ROW;
+                const char *p = base + (size_t)r * W * 2 + q * BYTES;
+                if (BYTES == 8) { uint2 d = *(const uint2 *)p; v[u] = d.x ^ d.y; }
+                else { uint4 d = *(const uint4 *)p; v[u] = d.x ^ d.y ^ d.z ^ d.w; }
+            }
+            acc += v[0] + v[1] + v[2] + v[3];
+        }
+    }
+    out[(blockIdx.x * (blockDim.x >> 6) + wave) * 64 + lane] = acc;
+}
+
+int main()
+{
+    const int W = 1920, H = 1080, F = 32;
+    char *plane; uint32_t *orig, *out;
+    CHECK(hipMalloc(&plane, (size_t)W * H * 2 * F));
+    CHECK(hipMemset(plane, 1, (size_t)W * H * 2 * F));
+    std::vector<uint32_t> o(65536);
+    uint32_t s = 12345;
+    const int blocks = 256 * 24, iters = 8;
+    for (int al = 0; al < 2; al++) {
+        for (auto &v : o) {                       // raster-ordered-ish: random frame, row band, column
+            s = s * 1664525u + 1013904223u; uint32_t f = (s >> 8) % F;
+            s = s * 1664525u + 1013904223u; uint32_t y = 40 + (s >> 8) % (H - 120);
+            s = s * 1664525u + 1013904223u; uint32_t x = 40 + (s >> 8) % (W - 160);
+            if (al) x &= ~7u;                     // 16-byte aligned windows
+            else x &= ~3u;                        // 8-byte aligned windows
+            v = ((f * H + y) * W + x) * 2;
+        }
+        CHECK(hipMalloc(&orig, o.size() * 4)); CHECK(hipMalloc(&out, blocks * 64 * 4 * 2));
+        CHECK(hipMemcpy(orig, o.data(), o.size() * 4, hipMemcpyHostToDevice));
+        for (int b = 0; b < 2; b++) {
+            if (b == 1 && al == 0) continue;      // 16-byte loads need 16-byte alignment
+            hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+            for (int rep = 0; rep < 2; rep++) {
+                CHECK(hipEventRecord(e0));
+                if (b == 0) k<8><<<blocks, 64>>>(plane, orig, out, W, iters);
+                else k<16><<<blocks, 64>>>(plane, orig, out, W, iters);
+                CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+            }
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            const int per_row = b == 0 ? 19 : 10;
+            const double ninstr = (double)blocks * iters * ((71 * per_row + 255) / 256) * 4;
+            if (b == 0 && al == 0) {
+                for (int wpb = 4; wpb <= 16; wpb *= 2) {
+                    for (int rep = 0; rep < 2; rep++) {
+                        CHECK(hipEventRecord(e0));
+                        k<8, 40><<<blocks / wpb, 64 * wpb>>>(plane, orig, out, W, iters);
+                        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+                    }
+                    float m2; CHECK(hipEventElapsedTime(&m2, e0, e1));
+                    printf("  %2d waves per block on neighbouring windows, 8-byte pieces: %.3f ms, %.1f ns per window per CU\n", wpb, m2,
+                           m2 * 1e6 / ((double)blocks * iters / 256));
+                    for (int rep = 0; rep < 2; rep++) {
+                        CHECK(hipEventRecord(e0));
+                        k<16, 40><<<blocks / wpb, 64 * wpb>>>(plane, orig, out, W, iters);
+                        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+                    }
+                    CHECK(hipEventElapsedTime(&m2, e0, e1));
+                    printf("  %2d waves per block on neighbouring windows, 16-byte pieces (unaligned): %.3f ms, %.1f ns per window per CU\n", wpb, m2,
+                           m2 * 1e6 / ((double)blocks * iters / 256));
+                }
+            }
+            printf("window as %2d-byte pieces (%s-aligned): %.3f ms, %.1f ns per window per CU, %.1f cycles@2.4GHz per wave-load per CU\n",
+                   b == 0 ? 8 : 16, al ? "16B" : "8B", ms, ms * 1e6 / ((double)blocks * iters / 256), ms * 1e-3 * 2.4e9 / (ninstr / 256));
+        }
+    }
+    return 0;
+}
