@@ -67,22 +67,30 @@ int main(int argc, char **argv)
     while (n < MAX_KEYPOINTS && kps[n].contrast) n++;
     printf("%dx%d: %d keypoints, %.3f ms (host buffers in, host buffers out)\n", W, H, n, ms);
 
-    // main.cpp:82-84: sort by contrast, keep the strongest MAX_FINAL_KEYPOINTS.  The reference's
-    // std::sort is unstable; ties are broken here by raster position.  Descriptors stay in raster
-    // order (main.cpp:82 does not permute them), so each sorted keypoint carries its raster index.
-    std::vector<int> order(n);
-    for (int i = 0; i < n; i++) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](int a, int b) {
-        return kps[a].contrast != kps[b].contrast ? kps[a].contrast > kps[b].contrast : a < b; });
-    const int keep = std::min(n, MAX_FINAL_KEYPOINTS);
+    // main.cpp:82-130: the MAX_FINAL_KEYPOINTS strongest keypoints in descending order of contrast,
+    // selected on the device.  The reference's std::sort is unstable; ties keep raster order here.
+    // Descriptors stay in raster order (main.cpp:82 does not permute them), so each final keypoint
+    // carries its slot.  The same selection on the host checks the device result.
+    std::vector<Keypoint_t> fin(MAX_FINAL_KEYPOINTS);
+    std::vector<uint32_t> slot(MAX_FINAL_KEYPOINTS);
+    const int nkp = sift_select_final_keypoints(kps, fin.data(), slot.data());
+    printf("number of keypoints = %d\n", nkp);                    // main.cpp:130
+    std::vector<int> order(MAX_KEYPOINTS);
+    for (int i = 0; i < MAX_KEYPOINTS; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return kps[a].contrast > kps[b].contrast; });
+    for (int i = 0; i < MAX_FINAL_KEYPOINTS; i++)
+        if ((int)slot[i] != order[i] || memcmp(&fin[i], &kps[order[i]], sizeof(Keypoint_t)) != 0) {
+            fprintf(stderr, "device selection differs from the host sort at rank %d\n", i);
+            return 1;
+        }
     if (argc > 2) {
         std::string p = argv[2];
         FILE *f = fopen((p + "_keypoints.txt").c_str(), "w");
         FILE *g = fopen((p + "_descriptors.txt").c_str(), "w");
         if (!f || !g) { fprintf(stderr, "cannot write outputs\n"); return 1; }
-        for (int i = 0; i < keep; i++) {
-            const int k = order[i];
-            fprintf(f, "%d %u %u %u\n", k, (unsigned)kps[k].x, (unsigned)kps[k].y, (unsigned)kps[k].contrast);
+        for (int i = 0; i < nkp; i++) {
+            const int k = (int)slot[i];
+            fprintf(f, "%d %u %u %u\n", k, (unsigned)fin[i].x, (unsigned)fin[i].y, (unsigned)fin[i].contrast);
             for (int j = 0; j < DESC_SIZE; j++) fprintf(g, "%u%c", (unsigned)desc[(size_t)k * DESC_SIZE + j], j + 1 < DESC_SIZE ? ' ' : '\n');
         }
         fclose(f); fclose(g);

@@ -20,3 +20,9 @@ void sift_shutdown(void);
 // Pinned host buffers, the counterpart of sds_alloc / sds_free (main.cpp:18-32, :214-217).
 void *sift_alloc(unsigned long bytes);
 void sift_free(void *p);
+// The keypoint post-processing of main.cpp:82-130 on the device: the MAX_FINAL_KEYPOINTS keypoints of
+// largest contrast in descending order (what std::sort with CompareContrast + memcpy leave in
+// pFinalKeypoints), equal contrasts in slot order.  pSlot (may be NULL) receives the slot of each
+// final keypoint in pKeypoints / pDesc.  Returns nKp, the number with x > 0 && y > 0 (:112-129).
+// pKeypoints itself is left as it is (the reference sorts it in place and never reads it again).
+int sift_select_final_keypoints(const Keypoint_t *pKeypoints, Keypoint_t *pFinalKeypoints, uint32_t *pSlot);

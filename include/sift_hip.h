@@ -95,6 +95,18 @@ int sift_hip_main_orientation(sift_hip_ctx *ctx, const sift_grad *grad, const si
 int sift_hip_descriptor(sift_hip_ctx *ctx, const sift_grad *grad, const sift_keypoint *kps, const uint8_t *ori,
                         uint32_t *desc);
 
+/* The keypoint post-processing of main.cpp:82-130: the nfinal (reference:
+ * MAX_FINAL_KEYPOINTS = 1000, SIFTParameters.hpp:24) slots of largest contrast of kps
+ * (max_keypoints slots, padding included), in descending order of contrast -- what
+ * std::sort(pKeypoints, ..., CompareContrast) + memcpy leave in pFinalKeypoints (:82-84).
+ * std::sort is not stable; here equal contrasts keep slot (= raster) order.
+ * index (optional): slot of final_kps[r] in kps / in the descriptor matrix;
+ * nvalid (optional): how many of them have x > 0 && y > 0 (nKp, main.cpp:112-129).
+ * 1 <= nfinal <= min(max_keypoints, 4096). */
+#define SIFT_HIP_MAX_FINAL_KEYPOINTS 1000
+int sift_hip_select_top(sift_hip_ctx *ctx, const sift_keypoint *kps, int nfinal, sift_keypoint *final_kps,
+                        uint32_t *index, uint32_t *nvalid);
+
 /* The image loop of main.cpp:37-210 as one call: frame f of `nframes` goes to
  * context f % nctx (one context per GPU), outputs land in the caller's
  * per-frame slots kps[f*max_keypoints], desc[f*max_keypoints*72].  Frames are
@@ -124,6 +136,16 @@ int sift_hip_main_orientation_dev(sift_hip_ctx *ctx, const sift_grad *d_grad, in
                                   const sift_keypoint *d_kps, uint8_t *d_ori, void *stream);
 int sift_hip_descriptor_dev(sift_hip_ctx *ctx, const sift_grad *d_grad, int nframes, const sift_keypoint *d_kps,
                             const uint8_t *d_ori, uint32_t *d_desc, void *stream);
+
+/* sift_hip_select_top on device buffers: d_kps nframes*max_keypoints -> d_final
+ * nframes*nfinal; optional d_index nframes*nfinal, d_nvalid nframes.  When d_desc
+ * (nframes*max_keypoints*72) and d_final_desc (nframes*nfinal*72) are given, the
+ * descriptor rows of the selected keypoints are gathered as well (the reference leaves the
+ * descriptor matrix in slot order, main.cpp:134-148, so row r of its file does not belong to
+ * final keypoint r; `index` is what links the two).  nframes is not bound by max_batch. */
+int sift_hip_select_top_dev(sift_hip_ctx *ctx, const sift_keypoint *d_kps, int nframes, int nfinal,
+                            sift_keypoint *d_final, uint32_t *d_index, uint32_t *d_nvalid, const uint32_t *d_desc,
+                            uint32_t *d_final_desc, void *stream);
 
 /* Block until everything this context enqueued has finished. */
 int sift_hip_sync(sift_hip_ctx *ctx);

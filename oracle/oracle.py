@@ -153,3 +153,14 @@ def fnv1a(buf):
     f.restype = C.c_uint64
     f.argtypes = [C.c_void_p, C.c_size_t]
     return "%016x" % f(a.ctypes.data, a.size)
+
+
+def select_top(kps, nfinal=1000):
+    """main.cpp:82-130 -> (final[nfinal], index[nfinal], nvalid); ties ordered by slot."""
+    kps = np.ascontiguousarray(kps)
+    final = np.zeros(nfinal, KP_DTYPE)
+    index = np.zeros(nfinal, np.uint32)
+    f = lib().orc_select_top
+    f.restype = C.c_int
+    nvalid = f(_p(kps), C.c_int(len(kps)), C.c_int(nfinal), _p(final), _p(index))
+    return final, index, nvalid

@@ -450,3 +450,31 @@ uint64_t orc_fnv1a(const uint8_t *p, size_t n)
     for (size_t i = 0; i < n; i++) h = (h ^ p[i]) * 0x100000001B3ULL;
     return h;
 }
+
+/* ---- post-processing of main.cpp:82-130 --------------------------------------------------
+ * std::sort(pKeypoints, pKeypoints + MAX_KEYPOINTS, CompareContrast) (:82, CompareContrast =
+ * contrast descending, :8-11), memcpy of the first MAX_FINAL_KEYPOINTS (:84), and the count
+ * of those with x > 0 && y > 0 (:112-129).  std::sort is not stable, so the reference leaves the
+ * order among equal contrasts to the library; this restatement (and the GPU path) orders
+ * ties by slot, i.e. by the raster order sift_detect emits.  index[r] = slot of final[r]. */
+typedef struct { uint32_t contrast, slot; } sel_key;
+static int sel_cmp(const void *a, const void *b)
+{
+    const sel_key *p = (const sel_key *)a, *q = (const sel_key *)b;
+    if (p->contrast != q->contrast) return p->contrast > q->contrast ? -1 : 1;
+    return p->slot < q->slot ? -1 : (p->slot > q->slot);
+}
+int orc_select_top(const orc_keypoint *kps, int n, int nfinal, orc_keypoint *final, uint32_t *index)
+{
+    sel_key *k = (sel_key *)malloc((size_t)n * sizeof(sel_key));
+    int nvalid = 0;
+    for (int i = 0; i < n; i++) { k[i].contrast = kps[i].contrast; k[i].slot = (uint32_t)i; }
+    qsort(k, (size_t)n, sizeof(sel_key), sel_cmp);
+    for (int r = 0; r < nfinal && r < n; r++) {
+        final[r] = kps[k[r].slot];
+        if (index) index[r] = k[r].slot;
+        if (final[r].x > 0 && final[r].y > 0) nvalid++;
+    }
+    free(k);
+    return nvalid;
+}

@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "lib", "libsift_hip.so")
 
 MAX_KEYPOINTS = 10000   # SIFTParameters.hpp:22
-DESC_SIZE = 72          # SIFTParameters.hpp:26
+DESC_SIZE = 72               # SIFTParameters.hpp:26
+MAX_FINAL_KEYPOINTS = 1000   # SIFTParameters.hpp:24
 NSTAGES = 5
 
 # Keypoint_t (SIFTParameters.hpp:79-85) and Grad_t (:88-92)
@@ -25,6 +26,7 @@ EXPORTS = (
     "sift_hip_create", "sift_hip_destroy", "sift_hip_last_error", "sift_hip_device_count",
     "sift_hip_host_alloc", "sift_hip_host_free",
     "sift_hip_detect_and_compute", "sift_hip_detect", "sift_hip_main_orientation", "sift_hip_descriptor",
+    "sift_hip_select_top", "sift_hip_select_top_dev",
     "sift_hip_batch", "sift_hip_detect_and_compute_dev", "sift_hip_detect_dev",
     "sift_hip_main_orientation_dev", "sift_hip_descriptor_dev", "sift_hip_sync", "sift_hip_debug_planes",
     "sift_hip_set_profiling", "sift_hip_stage_ms", "sift_hip_stage_name", "sift_hip_set_blur_rows",
@@ -81,6 +83,8 @@ def load_library():
     lib.sift_hip_detect_dev.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp]
     lib.sift_hip_main_orientation_dev.argtypes = [vp, vp, i32, vp, vp, vp]
     lib.sift_hip_descriptor_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    lib.sift_hip_select_top.argtypes = [vp, vp, i32, vp, vp, C.POINTER(C.c_uint32)]
+    lib.sift_hip_select_top_dev.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.sift_hip_sync.argtypes = [vp]
     lib.sift_hip_debug_planes.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     lib.sift_hip_set_profiling.argtypes = [vp, i32]

@@ -19,6 +19,7 @@
 #include "detect_kernel.h"
 #include "compact_kernel.h"
 #include "describe_kernel.h"
+#include "select_kernel.h"
 
 static_assert(sizeof(sift_keypoint) == 8 && sizeof(sift::kp_t) == 8, "Keypoint_t is 8 bytes");
 static_assert(sizeof(sift_grad) == 4, "Grad_t is 4 bytes");
@@ -178,6 +179,8 @@ struct sift_hip_ctx {
     uint32_t *d_total = nullptr;          // staging for host-buffer entry points
     uint32_t *d_total_ctx = nullptr;      // k_emit's uncapped count per frame, read by the fused describe kernel
     uint8_t *d_ori = nullptr;
+    sift::kp_t *d_final = nullptr;        // staging of sift_hip_select_top (1 frame, lazily allocated)
+    uint32_t *d_findex = nullptr, *d_nvalid = nullptr;
     uint2 *d_tab = nullptr, *d_qtab = nullptr;
     int ntab = 0, n2 = 0, n2pad = 0, qa = 0, qb = 0;
     int blur_rows = 0;
@@ -307,6 +310,15 @@ int check_ctx(const sift_hip_ctx *c)
     return SIFT_HIP_OK;
 }
 
+int ensure_select(sift_hip_ctx *c)
+{
+    const size_t n = (size_t)std::min(c->max_kp, (int)sift::SEL_MAX_FINAL);
+    if (!c->d_final) HIP_TRY(hipMalloc(&c->d_final, n * sizeof(sift::kp_t)));
+    if (!c->d_findex) HIP_TRY(hipMalloc(&c->d_findex, n * 4));
+    if (!c->d_nvalid) HIP_TRY(hipMalloc(&c->d_nvalid, 4));
+    return SIFT_HIP_OK;
+}
+
 int ensure_gradfull(sift_hip_ctx *c)
 {
     if (!c->d_gradfull) HIP_TRY(hipMalloc(&c->d_gradfull, c->npix * sizeof(uint32_t)));
@@ -415,7 +427,7 @@ void sift_hip_destroy(sift_hip_ctx *c)
     DevGuard g(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_img, c->d_pyr, c->d_zero, c->d_list, c->d_listcount, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_gradp,
-                    c->d_gradfull, c->d_kps, c->d_desc, c->d_total, c->d_total_ctx, c->d_ori, c->d_tab, c->d_qtab};
+                    c->d_gradfull, c->d_final, c->d_findex, c->d_nvalid, c->d_kps, c->d_desc, c->d_total, c->d_total_ctx, c->d_ori, c->d_tab, c->d_qtab};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &ps : c->prof)
         for (int i = 0; i < SIFT_HIP_NSTAGES; i++)
@@ -531,7 +543,47 @@ int sift_hip_descriptor_dev(sift_hip_ctx *c, const sift_grad *d_grad, int nframe
                                                                  nullptr, d_desc, s);
 }
 
+int sift_hip_select_top_dev(sift_hip_ctx *c, const sift_keypoint *d_kps, int nframes, int nfinal, sift_keypoint *d_final,
+                            uint32_t *d_index, uint32_t *d_nvalid, const uint32_t *d_desc, uint32_t *d_final_desc,
+                            void *stream)
+{
+    if (int r = check_ctx(c)) return r;
+    if (!d_kps || !d_final) return fail(SIFT_HIP_EINVAL, "null buffer");
+    if (nframes < 1) return fail(SIFT_HIP_EINVAL, "nframes must be >= 1");
+    if (nfinal < 1 || nfinal > c->max_kp || nfinal > sift::SEL_MAX_FINAL)
+        return fail(SIFT_HIP_EINVAL, "nfinal outside [1, min(max_keypoints, 4096)]");
+    if ((d_desc == nullptr) != (d_final_desc == nullptr))
+        return fail(SIFT_HIP_EINVAL, "d_desc and d_final_desc go together");
+    DevGuard g(c->device);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipLaunchKernelGGL(sift::k_select_top, dim3(nframes), dim3(sift::SEL_THREADS), 0, s, (const sift::kp_t *)d_kps,
+                       c->max_kp, nfinal, (sift::kp_t *)d_final, d_index, d_nvalid, d_desc, d_final_desc);
+    HIP_TRY(hipGetLastError());
+    return SIFT_HIP_OK;
+}
+
 /* ---- host-buffer entry points ------------------------------------------ */
+
+int sift_hip_select_top(sift_hip_ctx *c, const sift_keypoint *kps, int nfinal, sift_keypoint *final_kps, uint32_t *index,
+                        uint32_t *nvalid)
+{
+    if (int r = check_ctx(c)) return r;
+    if (!kps || !final_kps) return fail(SIFT_HIP_EINVAL, "null buffer");
+    if (nfinal < 1 || nfinal > c->max_kp || nfinal > sift::SEL_MAX_FINAL)
+        return fail(SIFT_HIP_EINVAL, "nfinal outside [1, min(max_keypoints, 4096)]");
+    DevGuard g(c->device);
+    hipStream_t s = c->stream;
+    if (int r = ensure_select(c)) return r;
+    HIP_TRY(hipMemcpyAsync(c->d_kps, kps, (size_t)c->max_kp * 8, hipMemcpyHostToDevice, s));
+    if (int r = sift_hip_select_top_dev(c, (const sift_keypoint *)c->d_kps, 1, nfinal, (sift_keypoint *)c->d_final,
+                                        c->d_findex, c->d_nvalid, nullptr, nullptr, s))
+        return r;
+    HIP_TRY(hipMemcpyAsync(final_kps, c->d_final, (size_t)nfinal * 8, hipMemcpyDeviceToHost, s));
+    if (index) HIP_TRY(hipMemcpyAsync(index, c->d_findex, (size_t)nfinal * 4, hipMemcpyDeviceToHost, s));
+    if (nvalid) HIP_TRY(hipMemcpyAsync(nvalid, c->d_nvalid, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SIFT_HIP_OK;
+}
 
 int sift_hip_detect_and_compute(sift_hip_ctx *c, const uint8_t *img, sift_keypoint *kps, uint32_t *desc, int contrastTh)
 {

@@ -71,6 +71,16 @@ void sift_detect_and_compute(Pixel_t *pSrcImageCam0, Keypoint_t *pKeypoints, Des
         die("sift_detect_and_compute");
 }
 
+int sift_select_final_keypoints(const Keypoint_t *pKeypoints, Keypoint_t *pFinalKeypoints, uint32_t *pSlot)
+{
+    std::lock_guard<std::mutex> l(g_mu);
+    uint32_t nkp = 0;
+    if (sift_hip_select_top(ctx(), (const sift_keypoint *)pKeypoints, MAX_FINAL_KEYPOINTS, (sift_keypoint *)pFinalKeypoints,
+                            pSlot, &nkp) != SIFT_HIP_OK)
+        die("sift_select_final_keypoints");
+    return (int)nkp;
+}
+
 void sift_detect(Pixel_t *pSrcImage, Grad_t *pGradients, Keypoint_t *pKeypoints, int contrastTh)
 {
     std::lock_guard<std::mutex> l(g_mu);

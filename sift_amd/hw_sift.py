@@ -11,7 +11,8 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import DESC_SIZE, GRAD_DTYPE, KP_DTYPE, MAX_KEYPOINTS, NSTAGES, check, load_library
+from .capi import (DESC_SIZE, GRAD_DTYPE, KP_DTYPE, MAX_FINAL_KEYPOINTS, MAX_KEYPOINTS, NSTAGES, check,
+                   load_library)
 
 
 def _vp(a):
@@ -105,7 +106,22 @@ class SiftContext:
         check(self._lib.sift_hip_descriptor(self._h, _vp(grad), _vp(kps), _vp(ori), _vp(desc)))
         return desc
 
+    def select_top(self, kps, nfinal=MAX_FINAL_KEYPOINTS):
+        """main.cpp:82-130 -> (pFinalKeypoints[nfinal], slot index[nfinal], nKp); equal contrasts keep slot order"""
+        kps = self._kps(kps)
+        final = np.empty(int(nfinal), KP_DTYPE)
+        index = np.empty(int(nfinal), np.uint32)
+        nvalid = C.c_uint32(0)
+        check(self._lib.sift_hip_select_top(self._h, _vp(kps), int(nfinal), _vp(final), _vp(index), C.byref(nvalid)))
+        return final, index, int(nvalid.value)
+
     # -- device-buffer entry points (pointers into this device's memory) -----------
+    def select_top_dev(self, d_kps, nframes, nfinal, d_final, d_index=None, d_nvalid=None, d_desc=None,
+                       d_final_desc=None, stream=None):
+        check(self._lib.sift_hip_select_top_dev(self._h, _dp(d_kps), int(nframes), int(nfinal), _dp(d_final),
+                                                _dp(d_index), _dp(d_nvalid), _dp(d_desc), _dp(d_final_desc),
+                                                _dp(stream)))
+
     def detect_and_compute_dev(self, d_imgs, nframes, d_kps, d_desc, d_total=None, contrastTh=15, stream=None):
         check(self._lib.sift_hip_detect_and_compute_dev(self._h, _dp(d_imgs), int(nframes), _dp(d_kps), _dp(d_desc),
                                                         _dp(d_total), int(contrastTh), _dp(stream)))

@@ -18,6 +18,7 @@ SYMS = {
     "compute_main_orientation": "_Z24compute_main_orientationP6Grad_tP10Keypoint_tPh",
     "compute_descriptor": "_Z18compute_descriptorP6Grad_tP10Keypoint_tPhPj",
     "sift_set_frame_size": "_Z19sift_set_frame_sizeii",
+    "sift_select_final_keypoints": "_Z27sift_select_final_keypointsPK10Keypoint_tPS_Pj",
 }
 
 
