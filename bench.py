@@ -45,6 +45,26 @@ def cpu_baseline(width, height, budget_s=12.0, max_frames=12):
             "sample": "%d synthetic %dx%d frames (seeds 1..%d), full pipeline, %.1f s" % (n, width, height, n, dt)}
 
 
+def cpu_baseline_parallel(width, height, frames_per_thread=2):
+    """The same oracle, one frame per call, frame-parallel over the host cores this process may use
+    (the reference is single-threaded; frames are independent).  ctypes releases the
+    GIL inside the C call, so plain threads run in parallel."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)), 64))
+    frames = [orc.synth_frame(1 + i % 12, width, height) for i in range(cores * frames_per_thread)]
+    with ThreadPoolExecutor(cores) as ex:
+        t0 = time.perf_counter()
+        list(ex.map(orc.detect_and_compute, frames))
+        dt = time.perf_counter() - t0
+    return {"value": len(frames) / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d synthetic %dx%d frames over %d threads, full pipeline, %.1f s" % (len(frames), width, height, cores, dt)}
+
+
 def load_traffic(kernel, workload):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json,
     written by tools/pmc_traffic.py from separate rocprofv3 --pmc runs), or None."""
@@ -170,6 +190,7 @@ def main():
             out["kernel_ms_per_step"] = stage
         if a.gpus == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H)
+            out["cpu_baseline_all_cores"] = cpu_baseline_parallel(W, H)
         print(json.dumps(out), flush=True)
     env.close()
 
