@@ -145,6 +145,79 @@ __device__ __forceinline__ void slide(uint32_t (&a)[ksize<WHICH>()][4], const ui
     });
 }
 
+// The tables are symmetric top to bottom (row R = row N-1-R), so one input row contributes the
+// same value to slot s and to slot N-1-s: it is computed once (dot4 chains from 0, hi plane
+// folded) and added to both with plain adds, which issue at twice the rate of a dot4.  The slots
+// are still updated in ascending order (slot s takes the old slot s+1), so the contributions of
+// the lower half stay in registers until the upper half has used them.
+template <int WHICH, int R>
+__device__ __forceinline__ void row_contrib(uint32_t (&c)[4], const uint32_t (&w)[4][5], const uint32_t (&init)[4])
+{
+#pragma unroll
+    for (int p = 0; p < 4; p++) c[p] = init[p];
+    static_for<0, 5>([&](auto jj) {
+        constexpr int j = jj;
+        constexpr uint32_t k = kdw<WHICH>(R, j, 0);
+        if constexpr (k != 0) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) c[p] = __builtin_amdgcn_udot4(w[p][j], k, c[p], false);
+        }
+    });
+    if constexpr (row_has_hi<WHICH, R>()) {
+        uint32_t h[4] = {0, 0, 0, 0};
+        static_for<0, 5>([&](auto jj) {
+            constexpr int j = jj;
+            constexpr uint32_t k = kdw<WHICH>(R, j, 1);
+            if constexpr (k != 0) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) h[p] = __builtin_amdgcn_udot4(w[p][j], k, h[p], false);
+            }
+        });
+#pragma unroll
+        for (int p = 0; p < 4; p++) c[p] = (h[p] << 8) + c[p];
+    }
+}
+
+template <int WHICH>
+constexpr bool table_is_symmetric()
+{
+    constexpr int N = ksize<WHICH>();
+    for (int r = 0; r < N; r++)
+        for (int j = 0; j < 5; j++)
+            for (int pl = 0; pl < 2; pl++)
+                if (kdw<WHICH>(r, j, pl) != kdw<WHICH>(N - 1 - r, j, pl)) return false;
+    return true;
+}
+
+template <int WHICH>
+__device__ __forceinline__ void slide_sym(uint32_t (&a)[ksize<WHICH>()][4], const uint32_t (&w)[4][5])
+{
+    constexpr int N = ksize<WHICH>(), C = N / 2;
+    static_assert(table_is_symmetric<WHICH>(), "rows R and N-1-R must be equal");
+    const uint32_t zero[4] = {0, 0, 0, 0};
+    uint32_t c[C][4];
+    // slots 0..C-1 (table rows N-1-s = rows s)
+    static_for<0, C>([&](auto ss) {
+        constexpr int s = ss;
+        row_contrib<WHICH, s>(c[s], w, zero);
+#pragma unroll
+        for (int p = 0; p < 4; p++) a[s][p] = a[s + 1][p] + c[s][p];
+    });
+    // the centre row has no partner: the chain starts from the old slot C+1
+    {
+        uint32_t t[4];
+        row_contrib<WHICH, C>(t, w, a[C + 1]);
+#pragma unroll
+        for (int p = 0; p < 4; p++) a[C][p] = t[p];
+    }
+    // slots C+1..N-1 (table rows N-1-s) reuse the contribution of slot N-1-s
+    static_for<C + 1, N>([&](auto ss) {
+        constexpr int s = ss;
+#pragma unroll
+        for (int p = 0; p < 4; p++) a[s][p] = (s == N - 1 ? BLUR_INIT : a[s + 1 < N ? s + 1 : s][p]) + c[N - 1 - s][p];
+    });
+}
+
 __device__ __forceinline__ uint32_t pack4_q15(const uint32_t (&a)[4])
 {
     // (a>>15) of four finished accumulators into one dword, pixel p in byte p
@@ -158,6 +231,8 @@ __device__ __forceinline__ uint32_t pack4_q15(const uint32_t (&a)[4])
 //
 // grid: x = ceil(W/4 / blockDim) blocks, y = strips, z = frames.  `zero_row` points at >= W bytes
 // of zeros: rows outside the image are read from there, so the row loads need no test.
+// GUARD: skip slot groups whose rows lie outside the strip (short strips: small batches).  Without
+// it every slot is updated in every iteration, through the symmetric scheme above (long strips).
 template <bool GUARD>
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, uint4 *__restrict__ pyr,
                                               const uint32_t *__restrict__ zero_row, int W, int H, int rows)
@@ -239,9 +314,9 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, 
             if (live(5, 6, 11)) slide<2, 6, 11>(a2, w);
             if (live(2, 0, 5)) slide<1, 0, 5>(a1, w);
         } else {
-            slide<3, 0, 19>(a3, w);
-            slide<2, 0, 11>(a2, w);
-            slide<1, 0, 5>(a1, w);
+            slide_sym<3>(a3, w);
+            slide_sym<2>(a2, w);
+            slide_sym<1>(a1, w);
         }
 
         // finished rows: G1 row i-2, G2 row i-5, G3 row i-9

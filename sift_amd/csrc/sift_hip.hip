@@ -184,6 +184,7 @@ struct sift_hip_ctx {
     uint2 *d_tab = nullptr, *d_qtab = nullptr;
     int ntab = 0, n2 = 0, n2pad = 0, qa = 0, qb = 0;
     int blur_rows = 0;
+    int blur_sym_rows = 48;               // strips at least this long run k_blur<false>
     // profiling: a ring of `nslots` calls, one HIP event pair per kernel of a call
     struct ProfSlot { hipEvent_t ev[SIFT_HIP_NSTAGES][2] = {}; bool used[SIFT_HIP_NSTAGES] = {}; };
     std::vector<ProfSlot> prof;
@@ -246,8 +247,14 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
         // 64-thread blocks when a row has few dword columns, so small frames still spread over CUs
         const int bs = (W / 4) >= 256 ? 256 : 64;
         dim3 grid(((W / 4) + bs - 1) / bs, (H + rows - 1) / rows, nframes);
-        hipLaunchKernelGGL(sift::k_blur<true>, grid, dim3(bs), 0, s, d_imgs, c->d_pyr,
-                           reinterpret_cast<const uint32_t *>(c->d_zero), W, H, rows);
+        // long strips: the 18 warm-up rows are a small share, every slot is updated in every
+        // iteration with the symmetric scheme; short strips skip the slots outside the strip
+        if (rows >= c->blur_sym_rows)
+            hipLaunchKernelGGL(sift::k_blur<false>, grid, dim3(bs), 0, s, d_imgs, c->d_pyr,
+                               reinterpret_cast<const uint32_t *>(c->d_zero), W, H, rows);
+        else
+            hipLaunchKernelGGL(sift::k_blur<true>, grid, dim3(bs), 0, s, d_imgs, c->d_pyr,
+                               reinterpret_cast<const uint32_t *>(c->d_zero), W, H, rows);
     }
     {
         StageTimer t(c, ST_DETECT, s);
