@@ -11,7 +11,7 @@
 //   3. rank of every selected slot by counting (contrast descending, then slot ascending).
 // std::sort is not stable: among equal contrasts the reference's order is whatever the
 // library's introsort leaves.  Here ties are ordered by slot -- the raster order sift_detect
-// emits -- and the oracle (orc_select_top) does the same.
+// emits -- and the tests' CPU restatement does the same.
 //
 // Padding slots (0, 0, 0) take part like in the reference: with fewer than nfinal valid
 // keypoints the tail of the output is zeros.
