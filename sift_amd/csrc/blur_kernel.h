@@ -254,6 +254,9 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, 
         const bool v = (q >= 0) && (q < W4);
         cm[k] = v ? 0xffffffffu : 0u;
         qc[k] = (uint32_t)(v ? q : xq) * 4u;
+        // a real register: left to itself the compiler keeps the condition in an SGPR pair, runs out
+        // of SGPRs (the dot4 weights live there) and reloads the pairs with v_readlane in the loop
+        asm volatile("" : "+v"(cm[k]));
     }
     auto row_ptr = [&](int i) -> const char * {      // wave-uniform
         return reinterpret_cast<const char *>((i >= 0 && i < H) ? img + (size_t)i * W4 : zero_row);

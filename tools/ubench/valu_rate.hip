@@ -44,7 +44,11 @@
     X(30, "v_dot2c_i32_i16 %0, %1, %2") \
     X(31, "v_mul_lo_u32 %0, %0, %1") \
     X(32, "v_min_u32 %0, %0, %1") \
-    X(33, "v_ashrrev_i32 %0, 1, %0")
+    X(33, "v_ashrrev_i32 %0, 1, %0") \
+    X(34, "v_sad_u32 %0, %1, %2, %0") \
+    X(35, "v_dot4_u32_u8 %0, %1, %2, %0\n\tv_add_u32 %0, %1, %0") \
+    X(36, "v_dot4_u32_u8 %0, %1, %2, %0\n\tv_dot4_u32_u8 %0, %1, %2, %0\n\tv_dot4_u32_u8 %0, %1, %2, %0\n\tv_add_u32 %0, %1, %0") \
+    X(37, "v_add_u32 %0, %1, %0\n\tv_lshlrev_b32 %0, 1, %0")
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed)
