@@ -31,6 +31,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace sift {
 
@@ -132,7 +133,6 @@ __device__ __forceinline__ int edge_at(const uint4 *__restrict__ fp, int W4, int
 constexpr int DETECT_ROWS = 32;                       // rows per strip
 constexpr int DETECT_QUEUE = 256 * DETECT_ROWS / 4;   // strict extrema are never 8-adjacent
 
-struct ColStat { int e0, e1, f0, f1, b0, b1; };       // rows y-1 (0) and y (1) of one column
 
 // grid: x = ceil(W/256) spans, y = strips of DETECT_ROWS, z = frames; block = 64 (one wave)
 template <bool FULLGRAD>
@@ -175,8 +175,11 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
     };
     auto masked = [](uint4 q, uint32_t m) { q.x &= m; q.y &= m; q.z &= m; q.w &= m; return q; };
 
-    ColStat st[4], hs;
-    uint32_t g2a = 0, g2b = 0, hg2b = 0;              // G2 dwords of rows y-1, y; halo group's G2 of row y
+    // Per column and row: e = max(D1, D3), f = min(D1, D3), b = D2.  Three rows are held (y-1, y,
+    // y+1) in three slots whose roles rotate: the loop body exists once per rotation phase, so no
+    // register is copied when the rows move up.
+    int se[3][4], sf[3][4], sb[3][4], he[3], hf[3], hb[3];
+    uint32_t g2[3], hg2[3];                           // G2 dwords of the lane's group and of the halo group
     auto stats = [&](const uint4 &Q, int p, int &e, int &f, int &b) {
         const int d1 = byte_of(Q.y, p) - byte_of(Q.x, p);
         const int d3 = byte_of(Q.w, p) - byte_of(Q.z, p);
@@ -184,69 +187,49 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
         e = max(d1, d3);
         f = min(d1, d3);
     };
-    // push row r into the state (rows shift up by one)
-    auto advance = [&](const uint4 &Q, const uint4 &Qh, int (&e2)[4], int (&f2)[4], int (&b2)[4], int &he2, int &hf2,
-                       int &hb2) {
+    // row r into slot k
+    auto push = [&](const uint4 &Q, const uint4 &Qh, int k) {
 #pragma unroll
-        for (int p = 0; p < 4; p++) stats(Q, p, e2[p], f2[p], b2[p]);
+        for (int p = 0; p < 4; p++) stats(Q, p, se[k][p], sf[k][p], sb[k][p]);
         // halo pixel: byte hp of each plane
         const uint32_t sh = (uint32_t)hp * 8u;
         const int hsrc = (int)((Qh.x >> sh) & 0xffu), h1 = (int)((Qh.y >> sh) & 0xffu);
         const int h2 = (int)((Qh.z >> sh) & 0xffu), h3 = (int)((Qh.w >> sh) & 0xffu);
         const int hd1 = h1 - hsrc, hd3 = h3 - h2;
-        hb2 = h2 - h1;
-        he2 = max(hd1, hd3);
-        hf2 = min(hd1, hd3);
-    };
-    auto shift_in = [&](const int (&e2)[4], const int (&f2)[4], const int (&b2)[4], int he2, int hf2, int hb2) {
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            st[p].e0 = st[p].e1; st[p].e1 = e2[p];
-            st[p].f0 = st[p].f1; st[p].f1 = f2[p];
-            st[p].b0 = st[p].b1; st[p].b1 = b2[p];
-        }
-        hs.e0 = hs.e1; hs.e1 = he2; hs.f0 = hs.f1; hs.f1 = hf2; hs.b0 = hs.b1; hs.b1 = hb2;
+        hb[k] = h2 - h1;
+        he[k] = max(hd1, hd3);
+        hf[k] = min(hd1, hd3);
+        g2[k] = Q.z;
+        hg2[k] = Qh.z;
     };
 
-    // prologue: rows ys-1 and ys
+    // prologue: rows ys-1 (slot 0) and ys (slot 1)
     uint4 Q, Qh, Qn, Qhn;
-    {
-        int e2[4], f2[4], b2[4], he2, hf2, hb2;
-#pragma unroll
-        for (int p = 0; p < 4; p++) st[p] = ColStat{0, 0, 0, 0, 0, 0};
-        hs = ColStat{0, 0, 0, 0, 0, 0};
-        load_row(ys - 1, Q, Qh);
-        Q = masked(Q, cmask); Qh = masked(Qh, hmask);
-        advance(Q, Qh, e2, f2, b2, he2, hf2, hb2);
-        shift_in(e2, f2, b2, he2, hf2, hb2);
-        g2b = Q.z;
-        load_row(ys, Q, Qh);
-        Q = masked(Q, cmask); Qh = masked(Qh, hmask);
-        advance(Q, Qh, e2, f2, b2, he2, hf2, hb2);
-        shift_in(e2, f2, b2, he2, hf2, hb2);
-        g2a = g2b; g2b = Q.z; hg2b = Qh.z;
-    }
+    load_row(ys - 1, Q, Qh);
+    push(masked(Q, cmask), masked(Qh, hmask), 0);
+    load_row(ys, Q, Qh);
+    push(masked(Q, cmask), masked(Qh, hmask), 1);
     load_row(ys + 1, Qn, Qhn);
 
     uint32_t qcount = 0;                              // wave-uniform
-    for (int y = ys; y < ye; ++y) {
+    // one image row; A, B, C = slots of rows y-1, y, y+1 (C is overwritten with row y+1)
+    auto row = [&](int y, auto ka, auto kb, auto kc) {
+        constexpr int A = decltype(ka)::value, B = decltype(kb)::value, C = decltype(kc)::value;
         Q = masked(Qn, cmask); Qh = masked(Qhn, hmask);                 // row y+1
         load_row(y + 2, Qn, Qhn);                                        // prefetch (a row past the strip is harmless)
-
-        int e2[4], f2[4], b2[4], he2, hf2, hb2;
-        advance(Q, Qh, e2, f2, b2, he2, hf2, hb2);
+        push(Q, Qh, C);
 
         // per column: max/min over the three rows
         int E[4], F[4], BA[4], BI[4];
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            E[p] = max(max(st[p].e0, st[p].e1), e2[p]);
-            F[p] = min(min(st[p].f0, st[p].f1), f2[p]);
-            BA[p] = max(max(st[p].b0, st[p].b1), b2[p]);
-            BI[p] = min(min(st[p].b0, st[p].b1), b2[p]);
+            E[p] = max(max(se[A][p], se[B][p]), se[C][p]);
+            F[p] = min(min(sf[A][p], sf[B][p]), sf[C][p]);
+            BA[p] = max(max(sb[A][p], sb[B][p]), sb[C][p]);
+            BI[p] = min(min(sb[A][p], sb[B][p]), sb[C][p]);
         }
-        const int hE = max(max(hs.e0, hs.e1), he2), hF = min(min(hs.f0, hs.f1), hf2);
-        const int hBA = max(max(hs.b0, hs.b1), hb2), hBI = min(min(hs.b0, hs.b1), hb2);
+        const int hE = max(max(he[A], he[B]), he[C]), hF = min(min(hf[A], hf[B]), hf[C]);
+        const int hBA = max(max(hb[A], hb[B]), hb[C]), hBI = min(min(hb[A], hb[B]), hb[C]);
         const int lE = from_left(hE, E[3]), lF = from_left(hF, F[3]);
         const int lBA = from_left(hBA, BA[3]), lBI = from_left(hBI, BI[3]);
         const int rE = from_right(hE, E[0]), rF = from_right(hF, F[0]);
@@ -260,9 +243,9 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
             const int Fl = p ? F[p - 1] : lF, Fr = p < 3 ? F[p + 1] : rF;
             const int BAl = p ? BA[p - 1] : lBA, BAr = p < 3 ? BA[p + 1] : rBA;
             const int BIl = p ? BI[p - 1] : lBI, BIr = p < 3 ? BI[p + 1] : rBI;
-            const int c = st[p].b1;
-            const int mx = max(max(max(El, E[p]), Er), max(max(BAl, BAr), max(st[p].b0, b2[p])));
-            const int mn = min(min(min(Fl, F[p]), Fr), min(min(BIl, BIr), min(st[p].b0, b2[p])));
+            const int c = sb[B][p];
+            const int mx = max(max(max(El, E[p]), Er), max(max(BAl, BAr), max(sb[A][p], sb[C][p])));
+            const int mn = min(min(min(Fl, F[p]), Fr), min(min(BIl, BIr), min(sb[A][p], sb[C][p])));
             const int ac = c < 0 ? -c : c;
             // strict 26-neighbour extremum (:245-304), |D2| >= contrastTh (:194), kpOut = |c| non-zero (:684)
             pre[p] = colvalid & ((c > mx) | (c < mn)) & (ac >= contrastTh) & (ac > 0);
@@ -285,8 +268,9 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
 
         // gradient of G2 at row y (:1189-1190): gx from the row itself, gy from rows y-1 and y+1
         // (the DPP shifts run with every lane active: a disabled source lane would leave `old`)
-        const uint32_t lw = (uint32_t)from_left((int)hg2b, (int)g2b);         // G2 dword of the group to the left
-        const uint32_t rw = (uint32_t)from_right((int)hg2b, (int)g2b);
+        const uint32_t g2b = g2[B];
+        const uint32_t lw = (uint32_t)from_left((int)hg2[B], (int)g2b);       // G2 dword of the group to the left
+        const uint32_t rw = (uint32_t)from_right((int)hg2[B], (int)g2b);
         if (colvalid) {
             uint32_t gp[4], gf[4];
 #pragma unroll
@@ -294,7 +278,7 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
                 const int right = p < 3 ? byte_of(g2b, p + 1) : byte_of(rw, 0);
                 const int left = p ? byte_of(g2b, p - 1) : byte_of(lw, 3);
                 const int gx = right - left;
-                const int gy = byte_of(Q.z, p) - byte_of(g2a, p);
+                const int gy = byte_of(g2[C], p) - byte_of(g2[A], p);
                 int ang, mag;
                 grad_code(gx, gy, ang, mag);
                 gp[p] = gradp_pack(ang, mag);
@@ -307,9 +291,16 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
             o.y = gp[2] | (gp[3] << 16);
             *reinterpret_cast<uint2 *>(gradp + fpix + (size_t)y * W + (size_t)g * 4) = o;
         }
-
-        shift_in(e2, f2, b2, he2, hf2, hb2);
-        g2a = g2b; g2b = Q.z; hg2b = Qh.z;
+    };
+    {
+        using K0 = std::integral_constant<int, 0>;
+        using K1 = std::integral_constant<int, 1>;
+        using K2 = std::integral_constant<int, 2>;
+        for (int y = ys; y < ye; y += 3) {
+            row(y, K0{}, K1{}, K2{});
+            if (y + 1 < ye) row(y + 1, K1{}, K2{}, K0{});
+            if (y + 2 < ye) row(y + 2, K2{}, K0{}, K1{});
+        }
     }
 
     // edge test on the queue, one lane per entry; survivors of it are compacted in place

@@ -35,6 +35,53 @@ __global__ void k(const char *plane, const uint32_t *origins, uint32_t *out, int
     out[(blockIdx.x * (blockDim.x >> 6) + wave) * 64 + lane] = acc;
 }
 
+// window as ROWS segments of PER_ROW 8-byte quads, segments PITCHMUL plane rows apart: the same bytes
+// in fewer, longer contiguous runs (what a row-interleaved plane layout would give)
+template <int ROWS, int PER_ROW, int PITCHMUL, int NEAR>
+__global__ void kshape(const char *plane, const uint32_t *origins, uint32_t *out, int W, int iters)
+{
+    constexpr int N = ROWS * PER_ROW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; it++) {
+        const char *base = plane + origins[(blockIdx.x * iters + it) & 0xffff];
+        if (NEAR) base += ((wave * 5) % NEAR) * W * 2 + ((wave * 12) % NEAR) * 2 / 8 * 8;
+        for (int i0 = 0; i0 < N; i0 += 256) {
+            uint32_t v[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                int i = i0 + u * 64 + lane;
+                i = i < N ? i : N - 1;
+                const int r = i / PER_ROW, q = i - r * PER_ROW;
+                uint2 d = *(const uint2 *)(base + (size_t)r * W * 2 * PITCHMUL + q * 8);
+                v[u] = d.x ^ d.y;
+            }
+            acc += v[0] + v[1] + v[2] + v[3];
+        }
+    }
+    out[(blockIdx.x * (blockDim.x >> 6) + wave) * 64 + lane] = acc;
+}
+
+template <int ROWS, int PER_ROW, int PITCHMUL>
+int shape_case(const char *plane, const uint32_t *orig, uint32_t *out, int W, int blocks, int iters)
+{
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    float m1 = 0, m8 = 0;
+    for (int rep = 0; rep < 2; rep++) {
+        CHECK(hipEventRecord(e0));
+        kshape<ROWS, PER_ROW, PITCHMUL, 0><<<blocks, 64>>>(plane, orig, out, W, iters);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&m1, e0, e1));
+        CHECK(hipEventRecord(e0));
+        kshape<ROWS, PER_ROW, PITCHMUL, 40><<<blocks / 8, 512>>>(plane, orig, out, W, iters);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&m8, e0, e1));
+    }
+    printf("shape %2d segments x %3d bytes, pitch x%d: random windows %.1f ns, neighbouring (8 waves/block) %.1f ns per window per CU\n",
+           ROWS, PER_ROW * 8, PITCHMUL, m1 * 1e6 / ((double)blocks * iters / 256), m8 * 1e6 / ((double)blocks * iters / 256));
+    return 0;
+}
+
 int main()
 {
     const int W = 1920, H = 1080, F = 32;
@@ -55,6 +102,12 @@ int main()
         }
         CHECK(hipMalloc(&orig, o.size() * 4)); CHECK(hipMalloc(&out, blocks * 64 * 4 * 2));
         CHECK(hipMemcpy(orig, o.data(), o.size() * 4, hipMemcpyHostToDevice));
+        if (al == 0) {
+            if (shape_case<71, 19, 1>(plane, orig, out, W, blocks, iters)) return 1;
+            if (shape_case<36, 38, 2>(plane, orig, out, W, blocks, iters)) return 1;
+            if (shape_case<18, 76, 4>(plane, orig, out, W, blocks, iters)) return 1;
+            if (shape_case<9, 152, 8>(plane, orig, out, W, blocks, iters)) return 1;
+        }
         for (int b = 0; b < 2; b++) {
             if (b == 1 && al == 0) continue;      // 16-byte loads need 16-byte alignment
             hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
