@@ -13,6 +13,7 @@
 #include <vector>
 #include <thread>
 #include <algorithm>
+#include <cmath>
 
 #include "../../include/sift_hip.h"
 #include "blur_kernel.h"
@@ -222,16 +223,25 @@ void begin_call(sift_hip_ctx *c)
 int pick_blur_rows(const sift_hip_ctx *c, int nframes)
 {
     if (c->blur_rows > 0) return c->blur_rows;
-    // enough strips to give every SIMD of the chip two waves, not more than
-    // needed: short strips re-run the 18 warm-up rows more often
-    const int waves_per_strip = ((c->W / 4) + 63) / 64;
-    const long want_waves = 256L * 4 * 2;
-    long strips = (want_waves + (long)waves_per_strip * nframes - 1) / ((long)waves_per_strip * nframes);
-    if (strips < 1) strips = 1;
-    int rows = (int)((c->H + strips - 1) / strips);
-    if (rows < 16) rows = 16;
-    if (rows > c->H) rows = c->H;
-    return rows;
+    // Strip length by a cost model fitted to measurements (tools/blur_rows_sweep.py): a wave
+    // runs rows + 18 warm-up iterations; k_blur<false> (long strips) pays 0.66 of k_blur<true>'s
+    // cost per iteration but all of the warm-up, k_blur<true> about half of it; the chip takes 1024
+    // waves at one per SIMD, a second wave per SIMD costs half as much again (measured), and what
+    // does not fit into 2048 waves runs after them.
+    const double waves_per_strip = (double)(((c->W / 4) + 63) / 64);
+    double best = 1e300;
+    int best_rows = c->H;
+    for (int k = 1; k <= (c->H + 5) / 6; k++) {
+        const int rows = (c->H + k - 1) / k;
+        if (rows < 6) break;
+        const double strips = (double)((c->H + rows - 1) / rows);
+        const double waves = waves_per_strip * strips * nframes;
+        const double per_wave = rows >= c->blur_sym_rows ? 0.66 * (rows + 18) : rows + 9.0;
+        const double full = std::floor(waves / 2048.0), rem = waves - 2048.0 * full;
+        const double cost = per_wave * (1.5 * full + (rem <= 0.0 ? 0.0 : rem <= 1024.0 ? 1.0 : 1.5));
+        if (cost < best * 0.999) { best = cost; best_rows = rows; }
+    }
+    return best_rows;
 }
 
 // blur -> detect -> cull -> emit on device-resident frames

@@ -51,6 +51,15 @@ def im0(golden_dir):
 @pytest.fixture(scope="session")
 def sift():
     """the product package; GPU tests fail (not skip) when the library or device is missing"""
+    # PyTorch's wheel carries its own HIP runtime.  When a test uses both, torch has to initialise
+    # first: after libsift_hip.so has brought up /opt/rocm's runtime, torch.cuda fails to initialise
+    # ("No HIP GPUs are available"); the other order works (INTEGRATION.md, section 5).
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     import sift_amd
     sift_amd.load_library()
     return sift_amd
