@@ -130,18 +130,18 @@ __device__ __forceinline__ int edge_at(const uint4 *__restrict__ fp, int W4, int
                           pyr_d2_at(fp, W4, W, H, y + 1, x - 1), pyr_d2_at(fp, W4, W, H, y + 1, x + 1), c);
 }
 
-constexpr int DETECT_ROWS = 32;                       // rows per strip
+constexpr int DETECT_ROWS = 32;                       // most rows per strip (LDS is sized for it)
 constexpr int DETECT_QUEUE = 256 * DETECT_ROWS / 4;   // strict extrema are never 8-adjacent
 
 
-// grid: x = ceil(W/256) spans, y = strips of DETECT_ROWS, z = frames; block = 64 (one wave)
+// grid: x = ceil(W/256) spans, y = strips of `rows` <= DETECT_ROWS, z = frames; block = 64 (one wave)
 template <bool FULLGRAD>
 __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, const uint4 *__restrict__ zero_row,
                                                u64 *__restrict__ candmask, uint32_t *__restrict__ keyplane,
                                                u64 *__restrict__ survmask, uint32_t *__restrict__ rowcount,
                                                uint32_t *__restrict__ list, uint32_t *__restrict__ listcount,
                                                uint16_t *__restrict__ gradp, uint32_t *__restrict__ gradfull,
-                                               int W, int H, int S, int contrastTh, int list_cap)
+                                               int W, int H, int S, int contrastTh, int list_cap, int rows)
 {
     __shared__ uint32_t queue[DETECT_QUEUE];
     __shared__ u64 cmap[DETECT_ROWS * 4];             // candidate bits of the strip: row-major, 4 words per row
@@ -149,8 +149,8 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
     const int lane = threadIdx.x;
     const int W4 = W >> 2;
     const int g = blockIdx.x * 64 + lane;             // 4-pixel group of this lane
-    const int ys = blockIdx.y * DETECT_ROWS;
-    const int ye = min(H, ys + DETECT_ROWS);
+    const int ys = blockIdx.y * rows;
+    const int ye = min(H, ys + rows);
     const int frame = blockIdx.z;
     const size_t fpix = (size_t)frame * (size_t)W * (size_t)H;
     const uint4 *__restrict__ fp = pyr + (fpix >> 2);

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -185,6 +186,7 @@ struct sift_hip_ctx {
     uint2 *d_tab = nullptr, *d_qtab = nullptr;
     int ntab = 0, n2 = 0, n2pad = 0, qa = 0, qb = 0;
     int blur_rows = 0;
+    int detect_rows = 0;                  // rows per k_detect strip (0 = heuristic)
     int blur_sym_rows = 48;               // strips at least this long run k_blur<false>
     // profiling: a ring of `nslots` calls, one HIP event pair per kernel of a call
     struct ProfSlot { hipEvent_t ev[SIFT_HIP_NSTAGES][2] = {}; bool used[SIFT_HIP_NSTAGES] = {}; };
@@ -268,15 +270,24 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
     }
     {
         StageTimer t(c, ST_DETECT, s);
-        dim3 grid((W + 255) / 256, (H + sift::DETECT_ROWS - 1) / sift::DETECT_ROWS, nframes);
+        // strips of up to DETECT_ROWS rows; shorter ones (2 extra rows of work per strip) when a
+        // small batch would otherwise leave most of the chip idle
+        const int spans = (W + 255) / 256;
+        int drows = c->detect_rows;
+        if (drows <= 0) {
+            const long strips = (768L + (long)spans * nframes - 1) / ((long)spans * nframes);   // measured: ~3 waves per CU suffice
+            drows = (int)((H + strips - 1) / strips);
+        }
+        drows = std::max(4, std::min(drows, (int)sift::DETECT_ROWS));
+        dim3 grid(spans, (H + drows - 1) / drows, nframes);
         if (d_gradfull)
             hipLaunchKernelGGL(sift::k_detect<true>, grid, dim3(64), 0, s, c->d_pyr, c->d_zero, c->d_cand, c->d_key,
                                c->d_surv, c->d_rowcount, c->d_list, c->d_listcount, c->d_gradp, d_gradfull, W, H, S,
-                               th, c->list_cap);
+                               th, c->list_cap, drows);
         else
             hipLaunchKernelGGL(sift::k_detect<false>, grid, dim3(64), 0, s, c->d_pyr, c->d_zero, c->d_cand, c->d_key,
                                c->d_surv, c->d_rowcount, c->d_list, c->d_listcount, c->d_gradp,
-                               (uint32_t *)nullptr, W, H, S, th, c->list_cap);
+                               (uint32_t *)nullptr, W, H, S, th, c->list_cap, drows);
     }
     {
         StageTimer t(c, ST_CULL, s);
@@ -427,6 +438,7 @@ int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int m
     A((void **)&c->d_tab, tab.size() * sizeof(uint2));
     c->ntab = (int)tab.size(); c->n2 = wt.n2; c->n2pad = wt.n2pad;
     c->qa = qt.qa; c->qb = qt.qb;
+    if (const char *v = getenv("SIFT_HIP_DETECT_ROWS")) c->detect_rows = atoi(v);   // tuning knob (tools/sweep_env.sh)
     A((void **)&c->d_qtab, qt.e.size() * sizeof(uint2));
     if (e == hipSuccess) e = hipMemcpy(c->d_qtab, qt.e.data(), qt.e.size() * sizeof(uint2), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_tab, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice);
