@@ -177,6 +177,8 @@ const char *sift_hip_stage_name(int stage);
 
 /* Tuning knob: rows per thread strip of the blur kernel (0 = heuristic). */
 int sift_hip_set_blur_rows(sift_hip_ctx *ctx, int rows);
+/* Tuning knob: rows per strip of the detect kernel (0 = heuristic; clamped to [4, 32]). */
+int sift_hip_set_detect_rows(sift_hip_ctx *ctx, int rows);
 
 #ifdef __cplusplus
 }

@@ -438,7 +438,6 @@ int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int m
     A((void **)&c->d_tab, tab.size() * sizeof(uint2));
     c->ntab = (int)tab.size(); c->n2 = wt.n2; c->n2pad = wt.n2pad;
     c->qa = qt.qa; c->qb = qt.qb;
-    if (const char *v = getenv("SIFT_HIP_DETECT_ROWS")) c->detect_rows = atoi(v);   // tuning knob (tools/sweep_env.sh)
     A((void **)&c->d_qtab, qt.e.size() * sizeof(uint2));
     if (e == hipSuccess) e = hipMemcpy(c->d_qtab, qt.e.data(), qt.e.size() * sizeof(uint2), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_tab, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice);
@@ -497,6 +496,14 @@ int sift_hip_set_blur_rows(sift_hip_ctx *c, int rows)
     if (int r = check_ctx(c)) return r;
     if (rows < 0) return fail(SIFT_HIP_EINVAL, "rows must be >= 0");
     c->blur_rows = rows;
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_set_detect_rows(sift_hip_ctx *c, int rows)
+{
+    if (int r = check_ctx(c)) return r;
+    if (rows < 0) return fail(SIFT_HIP_EINVAL, "rows must be >= 0");
+    c->detect_rows = rows;
     return SIFT_HIP_OK;
 }
 

@@ -158,6 +158,9 @@ class SiftContext:
     def set_blur_rows(self, rows):
         check(self._lib.sift_hip_set_blur_rows(self._h, int(rows)))
 
+    def set_detect_rows(self, rows):
+        check(self._lib.sift_hip_set_detect_rows(self._h, int(rows)))
+
     def stage_ms(self, back=0):
         """kernel times (ms) of the call `back` calls before the most recent one"""
         ms = (C.c_float * NSTAGES)()

@@ -249,3 +249,25 @@ def test_profiling_ring(sift, orc):
         ctx.set_profiling(0)
         with pytest.raises(sift.SiftHipError):
             ctx.stage_ms()
+
+
+def test_strip_lengths_do_not_change_results(sift, orc):
+    """The strip lengths of k_blur (both kernel variants) and k_detect are launch parameters picked by
+    heuristics that depend on the batch size; every choice must give the same bits."""
+    W, H = 640, 480
+    img = orc.synth_frame(5, W, H)
+    rk, rd, _ = orc.detect_and_compute(img)
+    n = nvalid(rk)
+    with sift.SiftContext(W, H) as ctx:
+        for rows in (1, 5, 6, 9, 17, 47, 48, 100, 479, 480, 1000):
+            ctx.set_blur_rows(rows)
+            kps, desc = ctx.sift_detect_and_compute(img)
+            assert (kps == rk).all() and (desc[:n] == rd[:n]).all(), "blur rows %d" % rows
+        ctx.set_blur_rows(0)
+        for rows in (1, 4, 5, 12, 31, 32, 33, 500):
+            ctx.set_detect_rows(rows)
+            kps, desc = ctx.sift_detect_and_compute(img)
+            assert (kps == rk).all() and (desc[:n] == rd[:n]).all(), "detect rows %d" % rows
+            grad, kps2 = ctx.sift_detect(img)
+            rg = orc.sift_detect(img)["grad"]
+            assert (kps2 == rk).all() and (grad["ang"] == rg["ang"]).all() and (grad["mag"] == rg["mag"]).all()
