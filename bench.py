@@ -151,6 +151,11 @@ def main():
     if not a.no_profile_events:
         recs = ctx.stage_ms_all()
         stage = {k: float(np.mean([r[k] for r in recs])) for k in sift_amd.STAGE_NAMES}
+        # spread over the timed steps: sum of the five kernels of a step (HIP events), per frame too
+        per_step = np.array([sum(r[k] for k in sift_amd.STAGE_NAMES) for r in recs])
+        spread = {"p5": float(np.percentile(per_step, 5)), "p50": float(np.percentile(per_step, 50)),
+                  "p95": float(np.percentile(per_step, 95)), "steps": int(len(per_step)),
+                  "what": "sum of the five kernels' HIP-event times per step, ms"}
     ctx.close()
 
     if env.rank == 0:
@@ -188,6 +193,7 @@ def main():
             out["valu"] = {"kernel": "k_blur", "achieved": macs / t_blur / 1e12, "peak": DOT4_PEAK_TMACS,
                            "unit": "TMAC/s (u8 dot4)", "frac": macs / t_blur / 1e12 / DOT4_PEAK_TMACS}
             out["kernel_ms_per_step"] = stage
+            out["step_kernel_ms"] = spread
         if a.gpus == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H)
             out["cpu_baseline_all_cores"] = cpu_baseline_parallel(W, H)
