@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--contrast-th", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the keypoint-count sanity check (kernel experiments)")
+    ap.add_argument("--no-overlap", action="store_true", help="skip the two-stream pass")
     ap.add_argument("--no-profile-events", action="store_true", help="leave the per-kernel HIP events out")
     a = ap.parse_args()
 
@@ -156,6 +157,39 @@ def main():
         spread = {"p5": float(np.percentile(per_step, 5)), "p50": float(np.percentile(per_step, 50)),
                   "p95": float(np.percentile(per_step, 95)), "steps": int(len(per_step)),
                   "what": "sum of the five kernels' HIP-event times per step, ms"}
+
+    # The same K steps again with the steps alternating between two contexts (two streams, two sets
+    # of scratch and output buffers): consecutive batches overlap on the GPU -- the texture-bound
+    # describe kernel of one batch runs beside the VALU-bound blur of the next.  Reported as
+    # "overlapped"; `value` and the per-kernel times above are the plain one-stream loop.
+    overlapped = None
+    if not a.no_overlap:
+        ctx2 = sift_amd.SiftContext(W, H, device=dev, max_batch=B)
+        d_kps2, d_desc2, d_tot2 = torch.zeros_like(d_kps), torch.zeros_like(d_desc), torch.zeros_like(d_tot)
+        ctx.set_profiling(0)
+        pair = ((ctx, d_kps, d_desc, d_tot), (ctx2, d_kps2, d_desc2, d_tot2))
+
+        def step2(k):
+            c, k_, d_, t_ = pair[k & 1]
+            c.detect_and_compute_dev(d_img, B, k_, d_, t_, a.contrast_th)
+
+        for k in range(2):
+            step2(k)
+        ctx.sync(); ctx2.sync()
+        env.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(a.steps):
+            step2(k)
+        ctx.sync(); ctx2.sync()
+        torch.cuda.synchronize()
+        env.barrier()
+        el2 = env.max_over_ranks(time.perf_counter() - t0)
+        ok2 = bool((d_tot2.cpu().numpy() == totals).all() and torch.equal(d_kps2, d_kps) and torch.equal(d_desc2, d_desc))
+        overlapped = {"streams": 2, "value": nframes / el2, "unit": "frames/s", "ms_per_step": 1e3 * el2 / a.steps,
+                      "outputs_equal_one_stream": ok2}
+        ctx2.close()
+
     ctx.close()
 
     if env.rank == 0:
@@ -194,6 +228,8 @@ def main():
                            "unit": "TMAC/s (u8 dot4)", "frac": macs / t_blur / 1e12 / DOT4_PEAK_TMACS}
             out["kernel_ms_per_step"] = stage
             out["step_kernel_ms"] = spread
+        if overlapped is not None:
+            out["overlapped"] = overlapped
         if a.gpus == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H)
             out["cpu_baseline_all_cores"] = cpu_baseline_parallel(W, H)
