@@ -114,6 +114,15 @@ int sift_hip_select_top(sift_hip_ctx *ctx, const sift_keypoint *kps, int nfinal,
 int sift_hip_batch(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *imgs, int nframes,
                    sift_keypoint *kps, uint32_t *desc, int contrastTh);
 
+/* The same loop with the post-processing of main.cpp:82-130 on the device: per frame only the
+ * nfinal strongest keypoints (descending contrast, ties in slot order), their slots, their
+ * descriptor rows and the count nKp travel back to the host -- 0.3 MB instead of 2.96 MB per frame
+ * at nfinal = 1000.  final_kps: nframes*nfinal; final_index, final_desc (nframes*nfinal*72), nvalid
+ * (nframes) may be NULL. */
+int sift_hip_batch_top(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *imgs, int nframes, int nfinal,
+                       sift_keypoint *final_kps, uint32_t *final_index, uint32_t *final_desc, uint32_t *nvalid,
+                       int contrastTh);
+
 /* ---- device-buffer entry points ------------------------------------------
  * Same work with inputs and outputs already resident in this context's device
  * memory (what the SDSoC data movers of DetectKeypoints.cpp:1054-1069 would

@@ -183,6 +183,9 @@ struct sift_hip_ctx {
     uint8_t *d_ori = nullptr;
     sift::kp_t *d_final = nullptr;        // staging of sift_hip_select_top (1 frame, lazily allocated)
     uint32_t *d_findex = nullptr, *d_nvalid = nullptr;
+    sift::kp_t *d_tfinal = nullptr;       // sift_hip_batch_top: selected keypoints of the chunks in flight (lazily allocated)
+    uint32_t *d_tindex = nullptr, *d_tdesc = nullptr, *d_tnvalid = nullptr;
+    size_t top_cap = 0;
     uint2 *d_tab = nullptr, *d_qtab = nullptr;
     int ntab = 0, n2 = 0, n2pad = 0, qa = 0, qb = 0;
     int blur_rows = 0;
@@ -455,7 +458,7 @@ void sift_hip_destroy(sift_hip_ctx *c)
     DevGuard g(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_img, c->d_pyr, c->d_zero, c->d_list, c->d_listcount, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_gradp,
-                    c->d_gradfull, c->d_final, c->d_findex, c->d_nvalid, c->d_kps, c->d_desc, c->d_total, c->d_total_ctx, c->d_ori, c->d_tab, c->d_qtab};
+                    c->d_gradfull, c->d_final, c->d_findex, c->d_nvalid, c->d_tfinal, c->d_tindex, c->d_tdesc, c->d_tnvalid, c->d_kps, c->d_desc, c->d_total, c->d_total_ctx, c->d_ori, c->d_tab, c->d_qtab};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &ps : c->prof)
         for (int i = 0; i < SIFT_HIP_NSTAGES; i++)
@@ -690,16 +693,49 @@ int sift_hip_descriptor(sift_hip_ctx *c, const sift_grad *grad, const sift_keypo
     return SIFT_HIP_OK;
 }
 
-int sift_hip_batch(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *imgs, int nframes, sift_keypoint *kps,
-                   uint32_t *desc, int contrastTh)
+}  // extern "C"
+
+namespace {
+
+// per-chunk device buffers of the selected keypoints (sift_hip_batch_top), two chunks in flight
+int ensure_top_buffers(sift_hip_ctx *c, int nfinal)
 {
-    if (!ctxs || nctx < 1 || !imgs || nframes < 0 || !kps || !desc) return fail(SIFT_HIP_EINVAL, "bad argument");
+    const size_t n = (size_t)c->max_batch * (size_t)nfinal;
+    if (c->top_cap >= n) return SIFT_HIP_OK;
+    for (void *p : {(void *)c->d_tfinal, (void *)c->d_tindex, (void *)c->d_tdesc, (void *)c->d_tnvalid}) if (p) (void)hipFree(p);
+    c->d_tfinal = nullptr; c->d_tindex = nullptr; c->d_tdesc = nullptr; c->d_tnvalid = nullptr; c->top_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_tfinal, n * sizeof(sift::kp_t)));
+    HIP_TRY(hipMalloc(&c->d_tindex, n * 4));
+    HIP_TRY(hipMalloc(&c->d_tdesc, n * 72 * 4));
+    HIP_TRY(hipMalloc(&c->d_tnvalid, (size_t)c->max_batch * 4));
+    c->top_cap = n;
+    return SIFT_HIP_OK;
+}
+
+// nfinal == 0: every keypoint slot and descriptor row goes back to the host (sift_hip_batch);
+// nfinal > 0: the frames' nfinal strongest keypoints, their slots and descriptor rows (sift_hip_batch_top)
+int batch_impl(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *imgs, int nframes, sift_keypoint *kps,
+               uint32_t *desc, int contrastTh, int nfinal, sift_keypoint *final_kps, uint32_t *final_index,
+               uint32_t *final_desc, uint32_t *nvalid)
+{
+    if (!ctxs || nctx < 1 || !imgs || nframes < 0) return fail(SIFT_HIP_EINVAL, "bad argument");
+    if (nfinal == 0 && (!kps || !desc)) return fail(SIFT_HIP_EINVAL, "bad argument");
+    if (nfinal != 0) {
+        if (!final_kps) return fail(SIFT_HIP_EINVAL, "final_kps is null");
+        if (nfinal < 1 || nfinal > ctxs[0]->max_kp || nfinal > sift::SEL_MAX_FINAL)
+            return fail(SIFT_HIP_EINVAL, "nfinal outside [1, min(max_keypoints, 4096)]");
+    }
     for (int i = 0; i < nctx; i++) {
         if (!ctxs[i]) return fail(SIFT_HIP_EINVAL, "null context");
         if (ctxs[i]->W != ctxs[0]->W || ctxs[i]->H != ctxs[0]->H || ctxs[i]->max_kp != ctxs[0]->max_kp)
             return fail(SIFT_HIP_EINVAL, "contexts differ in frame size or max_keypoints");
     }
     for (int f = 0; f < nframes; f++) if (!imgs[f]) return fail(SIFT_HIP_EINVAL, "null frame");
+    if (nfinal)
+        for (int i = 0; i < nctx; i++) {
+            DevGuard g(ctxs[i]->device);
+            if (int r = ensure_top_buffers(ctxs[i], nfinal)) return r;
+        }
     // one host thread per context (= per GPU); context i takes frames i, i+nctx, ...  No exchange
     // between contexts.  Inside a context the frames go through in chunks of half its max_batch,
     // double buffered: the H2D copy of chunk k+1 and the D2H copy of chunk k-1 run on their own
@@ -746,14 +782,29 @@ int sift_hip_batch(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *im
                 int r = sift_hip_detect_and_compute_dev(c, d_img, nb, (sift_keypoint *)d_kps, d_desc, c->d_total + (size_t)h * half,
                                                         contrastTh, s);
                 if (r) { rc[ci] = r; msg[ci] = g_err; }
+                if (!r && nfinal) {
+                    r = sift_hip_select_top_dev(c, (sift_keypoint *)d_kps, nb, nfinal,
+                                                (sift_keypoint *)(c->d_tfinal + (size_t)h * half * nfinal),
+                                                c->d_tindex + (size_t)h * half * nfinal, c->d_tnvalid + (size_t)h * half,
+                                                d_desc, c->d_tdesc + (size_t)h * half * nfinal * 72, s);
+                    if (r) { rc[ci] = r; msg[ci] = g_err; }
+                }
             }
             step(hipEventRecord(k_done[h], s), "record");
             // D2H
             step(hipStreamWaitEvent(s_out, k_done[h], 0), "wait");
             for (int k = 0; k < nb && rc[ci] == SIFT_HIP_OK; k++) {
                 const size_t f = (size_t)mine[b0 + k];
-                step(hipMemcpyAsync(kps + f * K, d_kps + (size_t)k * K, K * 8, hipMemcpyDeviceToHost, s_out), "D2H keypoints");
-                step(hipMemcpyAsync(desc + f * K * 72, d_desc + (size_t)k * K * 72, K * 72 * 4, hipMemcpyDeviceToHost, s_out), "D2H descriptors");
+                if (!nfinal) {
+                    step(hipMemcpyAsync(kps + f * K, d_kps + (size_t)k * K, K * 8, hipMemcpyDeviceToHost, s_out), "D2H keypoints");
+                    step(hipMemcpyAsync(desc + f * K * 72, d_desc + (size_t)k * K * 72, K * 72 * 4, hipMemcpyDeviceToHost, s_out), "D2H descriptors");
+                } else {
+                    const size_t NF = (size_t)nfinal, o = ((size_t)h * half + (size_t)k) * NF;
+                    step(hipMemcpyAsync(final_kps + f * NF, c->d_tfinal + o, NF * 8, hipMemcpyDeviceToHost, s_out), "D2H final keypoints");
+                    if (final_index) step(hipMemcpyAsync(final_index + f * NF, c->d_tindex + o, NF * 4, hipMemcpyDeviceToHost, s_out), "D2H slots");
+                    if (final_desc) step(hipMemcpyAsync(final_desc + f * NF * 72, c->d_tdesc + o * 72, NF * 72 * 4, hipMemcpyDeviceToHost, s_out), "D2H descriptor rows");
+                    if (nvalid) step(hipMemcpyAsync(nvalid + f, c->d_tnvalid + (size_t)h * half + (size_t)k, 4, hipMemcpyDeviceToHost, s_out), "D2H counts");
+                }
             }
             step(hipEventRecord(out_done[h], s_out), "record");
         }
@@ -778,6 +829,25 @@ int sift_hip_batch(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *im
     for (int i = 0; i < nctx; i++)
         if (rc[i] != SIFT_HIP_OK) return fail(rc[i], msg[i].c_str());
     return SIFT_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sift_hip_batch(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *imgs, int nframes, sift_keypoint *kps,
+                   uint32_t *desc, int contrastTh)
+{
+    return batch_impl(ctxs, nctx, imgs, nframes, kps, desc, contrastTh, 0, nullptr, nullptr, nullptr, nullptr);
+}
+
+int sift_hip_batch_top(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *imgs, int nframes, int nfinal,
+                       sift_keypoint *final_kps, uint32_t *final_index, uint32_t *final_desc, uint32_t *nvalid,
+                       int contrastTh)
+{
+    if (nfinal < 1) return fail(SIFT_HIP_EINVAL, "nfinal must be >= 1");
+    return batch_impl(ctxs, nctx, imgs, nframes, nullptr, nullptr, contrastTh, nfinal, final_kps, final_index, final_desc,
+                      nvalid);
 }
 
 int sift_hip_debug_planes(sift_hip_ctx *c, int frame, uint8_t *g1, uint8_t *g2, uint8_t *g3, uint16_t *cand,

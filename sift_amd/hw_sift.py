@@ -188,6 +188,23 @@ def batch(contexts, imgs, contrastTh=15):
     return kps, desc
 
 
+def batch_top(contexts, imgs, nfinal=MAX_FINAL_KEYPOINTS, contrastTh=15):
+    """sift_hip_batch_top: the image loop with main.cpp:82-130 on the device; returns
+    (final_kps[n,nfinal], slot[n,nfinal], final_desc[n,nfinal,72], nKp[n])."""
+    lib = load_library()
+    c0 = contexts[0]
+    imgs = [c0._img(im) for im in imgs]
+    n, NF = len(imgs), int(nfinal)
+    fin = np.empty((n, NF), KP_DTYPE)
+    idx = np.empty((n, NF), np.uint32)
+    fdesc = np.empty((n, NF, DESC_SIZE), np.uint32)
+    nv = np.empty(n, np.uint32)
+    hs = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    ps = (C.c_void_p * max(n, 1))(*[im.ctypes.data for im in imgs])
+    check(lib.sift_hip_batch_top(hs, len(contexts), ps, n, NF, _vp(fin), _vp(idx), _vp(fdesc), _vp(nv), int(contrastTh)))
+    return fin, idx, fdesc, nv
+
+
 # ---- module-level functions with the reference's names ---------------------------
 _default_ctx = {}
 

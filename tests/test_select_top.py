@@ -110,3 +110,21 @@ def test_gpu_pipeline_then_select_on_device(sift, orc):
             assert (fdesc[b, :rnv] == rd[ri[:rnv]]).all() and not fdesc[b, rnv:].any()
         with pytest.raises(sift.SiftHipError):
             ctx.select_top_dev(d_kps, B, NF, d_fin, d_idx, d_nv, d_desc, None)
+
+
+@pytest.mark.gpu
+def test_batch_top_is_batch_then_select(sift, orc):
+    """sift_hip_batch_top: ingest -> compute -> select -> compact egress, chunks double buffered."""
+    from sift_amd.hw_sift import batch_top
+    W, H, NF = 320, 240, 50
+    imgs = [orc.synth_frame(s, W, H) for s in range(40, 47)]
+    with sift.SiftContext(W, H, max_batch=4) as c0, sift.SiftContext(W, H, max_batch=1) as c1:
+        for ctxs in ([c0], [c0, c1]):
+            fin, idx, fdesc, nv = batch_top(ctxs, imgs, NF)
+            for f, img in enumerate(imgs):
+                rk, rd, _ = orc.detect_and_compute(img)
+                rf, ri, rnv = orc.select_top(rk, NF)
+                assert (fin[f] == rf).all() and (idx[f] == ri).all() and int(nv[f]) == rnv
+                assert (fdesc[f, :rnv] == rd[ri[:rnv]]).all() and not fdesc[f, rnv:].any()
+        with pytest.raises(sift.SiftHipError):
+            batch_top([c0], imgs, 0)

@@ -43,7 +43,20 @@ def main():
         dt = time.perf_counter() - t
         print("sift_hip_batch: %d frames, max_batch %d: %.1f ms -> %.0f frames/s (PCIe in + out included), kp[0]=%d"
               % (nframes, max_batch, dt * 1e3, nframes / dt, int((kps[0]["contrast"] > 0).sum())), flush=True)
+    NF = 1000
+    fin, pf = pinned(lib, (nframes, NF), sift_amd.KP_DTYPE)
+    idx, px = pinned(lib, (nframes, NF), np.uint32)
+    fdesc, pfd = pinned(lib, (nframes, NF, 72), np.uint32)
+    nv, pn = pinned(lib, (nframes,), np.uint32)
+    for rep in range(3):
+        t = time.perf_counter()
+        sift_amd.capi.check(lib.sift_hip_batch_top(hs, 1, ps, nframes, NF, vp(fin), vp(idx), vp(fdesc), vp(nv), 15))
+        dt = time.perf_counter() - t
+        print("sift_hip_batch_top (1000 strongest keypoints + their descriptor rows back): %d frames: %.1f ms -> %.0f frames/s, nKp[0]=%d"
+              % (nframes, dt * 1e3, nframes / dt, int(nv[0])), flush=True)
     ctx.close()
+    for p in (pf, px, pfd, pn):
+        lib.sift_hip_host_free(p)
     for p in (pi, pk, pd):
         lib.sift_hip_host_free(p)
 
