@@ -328,6 +328,9 @@ int run_describe(sift_hip_ctx *c, const void *d_grad, int nframes, const sift::k
     else if ((int)grid.x == c->max_kp)
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
                            d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->d_qtab, c->qa, c->qb, tot, c->W, c->H, c->max_kp);
+    else if (GFMT == sift::GRAD_PACKED16 && c->qa == 5 * 64 && c->qb == 11 * 64)
+        hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true, 5, 11>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->d_qtab, c->qa, c->qb, tot, c->W, c->H, c->max_kp);
     else
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
                            d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->d_qtab, c->qa, c->qb, tot, c->W, c->H, c->max_kp);
