@@ -87,7 +87,7 @@ template <int GFMT, int MODE, bool LOOP = false, int NA = 0, int NB = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_describe(const void *__restrict__ gradv, const kp_t *__restrict__ kps,
                                                  const uint8_t *__restrict__ ori_in, uint8_t *__restrict__ ori_out,
                                                  uint32_t *__restrict__ desc, const uint2 *__restrict__ tab,
-                                                 int n2, int n2pad, int ntab, const uint2 *__restrict__ qtab,
+                                                 int n2, int n2pad, int ntab, const void *__restrict__ qtab,
                                                  int qa, int qb, const uint32_t *__restrict__ total, int W, int H,
                                                  int max_kp)
 {
@@ -218,7 +218,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
             add((ovsel & 0x400u) | (rl | (9u << 9)), v);
         }
     };
-    auto quad_chunk = [&](auto two, auto nu, const char *gq, const char *tq, int t0) {
+    // part B entries are one dword: window row | quad of the row << 7 | 4 x c1 << 12
+    const uint32_t rowbytes = (uint32_t)W * 2u;
+    auto b_offset = [&](uint32_t e) { return (e & 0x7fu) * rowbytes + ((e >> 4) & 0xf8u); };
+    auto b_pixels = [&](uint32_t e, uint2 q) {
+        const std::false_type one;
+        quad_pixel(one, q.x & 0xffffu, e >> 12, 0u);
+        quad_pixel(one, q.x >> 16, e >> 16, 0u);
+        quad_pixel(one, q.y & 0xffffu, e >> 20, 0u);
+        quad_pixel(one, q.y >> 16, e >> 24, 0u);
+    };
+    auto a_pixels = [&](uint2 e, uint2 q) {
+        const std::true_type two;
+        quad_pixel(two, q.x & 0xffffu, e.y, e.x >> 14);
+        quad_pixel(two, q.x >> 16, e.y >> 8, e.x >> 15);
+        quad_pixel(two, q.y & 0xffffu, e.y >> 16, e.x >> 16);
+        quad_pixel(two, q.y >> 16, e.y >> 24, e.x >> 17);
+    };
+    // tq: this phase's table, qa 8-byte entries (part A) followed by qb 4-byte entries (part B)
+    auto chunk_a = [&](auto nu, const char *gq, const char *tq, int t0) {
         constexpr int N = decltype(nu)::value;
         uint2 e[N], q[N];
         const uint32_t tb = (uint32_t)(t0 + lane) * 8u;
@@ -227,36 +245,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
 #pragma unroll
         for (int u = 0; u < N; u++) q[u] = *reinterpret_cast<const uint2 *>(gq + (e[u].x & 0xffffffu));
 #pragma unroll
-        for (int u = 0; u < N; u++) {
-            quad_pixel(two, q[u].x & 0xffffu, e[u].y, e[u].x >> 14);
-            quad_pixel(two, q[u].x >> 16, e[u].y >> 8, e[u].x >> 15);
-            quad_pixel(two, q[u].y & 0xffffu, e[u].y >> 16, e[u].x >> 16);
-            quad_pixel(two, q[u].y >> 16, e[u].y >> 24, e[u].x >> 17);
-        }
+        for (int u = 0; u < N; u++) a_pixels(e[u], q[u]);
+    };
+    auto chunk_b = [&](auto nu, const char *gq, const char *tb0, int t0) {
+        constexpr int N = decltype(nu)::value;
+        uint32_t e[N];
+        uint2 q[N];
+        const uint32_t tb = (uint32_t)(t0 + lane) * 4u;
+#pragma unroll
+        for (int u = 0; u < N; u++) e[u] = *reinterpret_cast<const uint32_t *>(tb0 + tb + (uint32_t)u * 256u);
+#pragma unroll
+        for (int u = 0; u < N; u++) q[u] = *reinterpret_cast<const uint2 *>(gq + b_offset(e[u]));
+#pragma unroll
+        for (int u = 0; u < N; u++) b_pixels(e[u], q[u]);
     };
     // A wave's time is mostly load latency (table entry -> quad -> adds), so the static variant
     // issues all NA + NB table loads, then all gathers, and only then starts adding.
     auto quad_static = [&](const char *gq, const char *tq) {
-        constexpr int N = NA + NB > 0 ? NA + NB : 1;
-        uint2 e[N], q[N];
-        const uint32_t tb = (uint32_t)lane * 8u;
+        constexpr int MA = NA > 0 ? NA : 1, MB = NB > 0 ? NB : 1;
+        uint2 ea[MA], qa_[MA], qb_[MB];
+        uint32_t eb[MB];
+        const char *tb0 = tq + (size_t)NA * 512u;
 #pragma unroll
-        for (int u = 0; u < N; u++) e[u] = *reinterpret_cast<const uint2 *>(tq + tb + (uint32_t)u * 512u);
+        for (int u = 0; u < NA; u++) ea[u] = *reinterpret_cast<const uint2 *>(tq + (uint32_t)lane * 8u + (uint32_t)u * 512u);
 #pragma unroll
-        for (int u = 0; u < N; u++) q[u] = *reinterpret_cast<const uint2 *>(gq + (e[u].x & 0xffffffu));
-        static_for<0, N>([&](auto uu) {
-            constexpr int u = uu;
-            std::integral_constant<bool, (u < NA)> two;
-            quad_pixel(two, q[u].x & 0xffffu, e[u].y, e[u].x >> 14);
-            quad_pixel(two, q[u].x >> 16, e[u].y >> 8, e[u].x >> 15);
-            quad_pixel(two, q[u].y & 0xffffu, e[u].y >> 16, e[u].x >> 16);
-            quad_pixel(two, q[u].y >> 16, e[u].y >> 24, e[u].x >> 17);
-        });
+        for (int u = 0; u < NB; u++) eb[u] = *reinterpret_cast<const uint32_t *>(tb0 + (uint32_t)lane * 4u + (uint32_t)u * 256u);
+#pragma unroll
+        for (int u = 0; u < NA; u++) qa_[u] = *reinterpret_cast<const uint2 *>(gq + (ea[u].x & 0xffffffu));
+#pragma unroll
+        for (int u = 0; u < NB; u++) qb_[u] = *reinterpret_cast<const uint2 *>(gq + b_offset(eb[u]));
+#pragma unroll
+        for (int u = 0; u < NA; u++) a_pixels(ea[u], qa_[u]);
+#pragma unroll
+        for (int u = 0; u < NB; u++) b_pixels(eb[u], qb_[u]);
     };
-    auto quad_part = [&](auto two, const char *gq, const char *tq, int begin, int end) {
-        int t0 = begin;
-        for (; t0 + 64 * U <= end; t0 += 64 * U) quad_chunk(two, std::integral_constant<int, U>{}, gq, tq, t0);
-        for (; t0 < end; t0 += 64) quad_chunk(two, std::integral_constant<int, 1>{}, gq, tq, t0);
+    auto quad_loops = [&](const char *gq, const char *tq) {
+        int t0 = 0;
+        for (; t0 + 64 * U <= qa; t0 += 64 * U) chunk_a(std::integral_constant<int, U>{}, gq, tq, t0);
+        for (; t0 < qa; t0 += 64) chunk_a(std::integral_constant<int, 1>{}, gq, tq, t0);
+        const char *tb0 = tq + (size_t)qa * 8u;
+        t0 = 0;
+        for (; t0 + 64 * U <= qb; t0 += 64 * U) chunk_b(std::integral_constant<int, U>{}, gq, tb0, t0);
+        for (; t0 < qb; t0 += 64) chunk_b(std::integral_constant<int, 1>{}, gq, tb0, t0);
     };
 
     // the window is rows py-35..py+35 at columns px-35..px+35 of a linearly addressed plane
@@ -264,13 +294,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     if (PACK && inside && origin + 70L * W + 76 <= npix) {
         const int phase = (px - 35) & 3;             // = origin & 3 because W % 4 == 0
         const char *gq = gplane + (origin - phase) * 2;
-        const char *tq = reinterpret_cast<const char *>(qtab + (size_t)phase * (size_t)(qa + qb));
-        if constexpr (NA + NB > 0) {
-            quad_static(gq, tq);
-        } else {
-            quad_part(std::true_type{}, gq, tq, 0, qa);
-            quad_part(std::false_type{}, gq, tq, qa, qa + qb);
-        }
+        const char *tq = reinterpret_cast<const char *>(qtab) + (size_t)phase * ((size_t)qa * 8u + (size_t)qb * 4u);
+        if constexpr (NA + NB > 0) quad_static(gq, tq);
+        else quad_loops(gq, tq);
     } else if (inside) {
         sweep(std::false_type{});
     } else {

@@ -97,8 +97,9 @@ WindowTable build_window_table(int W)
 
 // Quad table of the describe kernel's fast path (describe_kernel.h): for each alignment
 // phase, the aligned 4-pixel quads of the 71-row window that hold a union pixel; quads with a
-// two-circle pixel first (qa entries after padding), then the rest (qb).
-struct QuadTable { std::vector<uint2> e; int qa = 0, qb = 0, kmax = 0; };
+// two-circle pixel first (part A: qa entries after padding, 8 bytes each), then the rest (part B:
+// qb entries, 4 bytes each: window row | quad of the row << 7 | 4 x circle id << 12).
+struct QuadTable { std::vector<uint32_t> words; int qa = 0, qb = 0, kmax = 0; };
 QuadTable build_quad_table(int W)
 {
     int c1[71][71], c2[71][71];
@@ -110,24 +111,24 @@ QuadTable build_quad_table(int W)
                 int y = SIFT_YSTART[n] + i, x = SIFT_XSTART[n] + j;
                 if (c1[y][x] == 10) c1[y][x] = n; else c2[y][x] = n;
             }
-    std::vector<uint2> A[4], B[4];
+    struct Quad { int y, q, a[4], b[4]; };
+    std::vector<Quad> A[4], B[4];
     size_t na = 0, nb = 0;
     for (int ph = 0; ph < 4; ph++) {
         for (int y = 0; y < 71; y++)
             for (int q = 0; q < 19; q++) {
-                uint32_t lo = (uint32_t)(y * W * 2 + q * 8), hi = 0;
+                Quad e;
+                e.y = y; e.q = q;
                 bool any = false, two = false;
                 for (int p = 0; p < 4; p++) {
                     const int x = q * 4 + p - ph;                  // window column of this pixel
-                    int a = 10, b = 10;
-                    if (x >= 0 && x < 71) { a = c1[y][x]; b = c2[y][x]; }
-                    any |= a != 10;
-                    two |= b != 10;
-                    hi |= (uint32_t)(a | b << 4) << (8 * p);
-                    if (b == 10) lo |= 1u << (24 + p);             // notov: the third add goes to the spare rows
+                    e.a[p] = e.b[p] = 10;
+                    if (x >= 0 && x < 71) { e.a[p] = c1[y][x]; e.b[p] = c2[y][x]; }
+                    any |= e.a[p] != 10;
+                    two |= e.b[p] != 10;
                 }
-                if (two) A[ph].push_back(make_uint2(lo, hi));
-                else if (any) B[ph].push_back(make_uint2(lo, hi));
+                if (two) A[ph].push_back(e);
+                else if (any) B[ph].push_back(e);
             }
         na = std::max(na, A[ph].size());
         nb = std::max(nb, B[ph].size());
@@ -135,26 +136,36 @@ QuadTable build_quad_table(int W)
     QuadTable t;
     t.qa = (int)((na + 63) / 64 * 64);
     t.qb = (int)((nb + 63) / 64 * 64);
-    const uint2 nop = make_uint2(0xfu << 24, 0xaaaaaaaau);          // offset 0, every pixel -> spare rows
+    const Quad nop = {0, 0, {10, 10, 10, 10}, {10, 10, 10, 10}};   // offset 0, every pixel -> spare rows
     for (int ph = 0; ph < 4; ph++) {
         A[ph].resize((size_t)t.qa, nop);
         B[ph].resize((size_t)t.qb, nop);
         // pixels per (LDS column, circle | overlap) of this phase; entry i falls to column i % 32
         int k[32][10];
         memset(k, 0, sizeof k);
-        for (int part = 0; part < 2; part++) {
-            const std::vector<uint2> &L = part ? B[ph] : A[ph];
-            for (size_t i = 0; i < L.size(); i++)
-                for (int p = 0; p < 4; p++) {
-                    const int a = (L[i].y >> (8 * p)) & 15, b = (L[i].y >> (8 * p + 4)) & 15;
-                    if (a < 9) k[i % 32][a]++;
-                    if (!part && b < 9) { k[i % 32][b]++; k[i % 32][9]++; }
-                }
+        for (size_t i = 0; i < A[ph].size(); i++) {
+            const Quad &e = A[ph][i];
+            uint32_t lo = (uint32_t)(e.y * W * 2 + e.q * 8), hi = 0;
+            for (int p = 0; p < 4; p++) {
+                if (e.a[p] < 9) k[i % 32][e.a[p]]++;
+                if (e.b[p] < 9) { k[i % 32][e.b[p]]++; k[i % 32][9]++; }
+                hi |= (uint32_t)(e.a[p] | e.b[p] << 4) << (8 * p);
+                if (e.b[p] == 10) lo |= 1u << (24 + p);            // notov: the third add goes to the spare rows
+            }
+            t.words.push_back(lo);
+            t.words.push_back(hi);
+        }
+        for (size_t i = 0; i < B[ph].size(); i++) {
+            const Quad &e = B[ph][i];
+            uint32_t w = (uint32_t)e.y | (uint32_t)e.q << 7;
+            for (int p = 0; p < 4; p++) {
+                if (e.a[p] < 9) k[i % 32][e.a[p]]++;
+                w |= (uint32_t)e.a[p] << (12 + 4 * p);
+            }
+            t.words.push_back(w);
         }
         for (int c = 0; c < 32; c++)
             for (int n = 0; n < 10; n++) t.kmax = std::max(t.kmax, k[c][n]);
-        t.e.insert(t.e.end(), A[ph].begin(), A[ph].end());
-        t.e.insert(t.e.end(), B[ph].begin(), B[ph].end());
     }
     return t;
 }
@@ -186,7 +197,8 @@ struct sift_hip_ctx {
     sift::kp_t *d_tfinal = nullptr;       // sift_hip_batch_top: selected keypoints of the chunks in flight (lazily allocated)
     uint32_t *d_tindex = nullptr, *d_tdesc = nullptr, *d_tnvalid = nullptr;
     size_t top_cap = 0;
-    uint2 *d_tab = nullptr, *d_qtab = nullptr;
+    uint2 *d_tab = nullptr;
+    uint32_t *d_qtab = nullptr;           // quad table (build_quad_table)
     int ntab = 0, n2 = 0, n2pad = 0, qa = 0, qb = 0;
     int blur_rows = 0;
     int detect_rows = 0;                  // rows per k_detect strip (0 = heuristic)
@@ -444,8 +456,8 @@ int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int m
     A((void **)&c->d_tab, tab.size() * sizeof(uint2));
     c->ntab = (int)tab.size(); c->n2 = wt.n2; c->n2pad = wt.n2pad;
     c->qa = qt.qa; c->qb = qt.qb;
-    A((void **)&c->d_qtab, qt.e.size() * sizeof(uint2));
-    if (e == hipSuccess) e = hipMemcpy(c->d_qtab, qt.e.data(), qt.e.size() * sizeof(uint2), hipMemcpyHostToDevice);
+    A((void **)&c->d_qtab, qt.words.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(c->d_qtab, qt.words.data(), qt.words.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_tab, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         sift_hip_destroy(c);
