@@ -67,6 +67,21 @@ __device__ __forceinline__ void grad_code(int gx, int gy, int &ang, int &mag)
     ang = p ? a : 0;
 }
 
+// gradp_pack(grad_code(gx, gy)) in one go: with a - 1 = 4 sy + 2 x + t (see grad_code) the word is
+// mag | (2 sy + x) << 9 | t << 15, and 0 where gx * gy == 0
+__device__ __forceinline__ uint32_t grad_word(int gx, int gy)
+{
+    const int gx2 = gx * gx, gy2 = gy * gy;
+    const uint32_t mag = (uint32_t)(int)__builtin_amdgcn_sqrtf((float)(gx2 + gy2) + 0.5f);
+    const int p = gx * gy;
+    const int xm = p >> 31;
+    const int dd = ((gx2 - gy2) ^ xm) - xm;
+    const uint32_t t = (uint32_t)(dd - 1) >> 31;
+    const uint32_t sy = (uint32_t)gy >> 31;
+    const uint32_t w = mag | (((sy << 1) | ((uint32_t)xm & 1u)) << 9) | (t << 15);
+    return p ? w : 0u;
+}
+
 __device__ __forceinline__ int byte_of(uint32_t w, int p) { return (int)((w >> (8 * p)) & 0xffu); }
 
 // lane i <- lane i-1 (wave_shr:1) / lane i+1 (wave_shl:1); lanes without a source keep `old`
@@ -212,6 +227,7 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
     load_row(ys + 1, Qn, Qhn);
 
     uint32_t qcount = 0;                              // wave-uniform
+    const int th1 = max(contrastTh, 1);               // |D2| >= contrastTh (:194) and |D2| != 0 (:684) in one test
     // one image row; A, B, C = slots of rows y-1, y, y+1 (C is overwritten with row y+1)
     auto row = [&](int y, auto ka, auto kb, auto kc) {
         constexpr int A = decltype(ka)::value, B = decltype(kb)::value, C = decltype(kc)::value;
@@ -236,7 +252,6 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
         const int rBA = from_right(hBA, BA[0]), rBI = from_right(hBI, BI[0]);
 
         bool pre[4];
-        uint32_t nib = 0;
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             const int El = p ? E[p - 1] : lE, Er = p < 3 ? E[p + 1] : rE;
@@ -248,15 +263,15 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
             const int mn = min(min(min(Fl, F[p]), Fr), min(min(BIl, BIr), min(sb[A][p], sb[C][p])));
             const int ac = c < 0 ? -c : c;
             // strict 26-neighbour extremum (:245-304), |D2| >= contrastTh (:194), kpOut = |c| non-zero (:684)
-            pre[p] = colvalid & ((c > mx) | (c < mn)) & (ac >= contrastTh) & (ac > 0);
-            nib |= pre[p] ? (1u << p) : 0u;
+            pre[p] = colvalid & ((c > mx) | (c < mn)) & (ac >= th1);
         }
 
-        const bool anypre = __ballot(nib != 0) != 0ull;
-        if (anypre) {
+        // the lane masks of the four tests are scalar values already: no vector work to combine them
+        const u64 pm[4] = {__ballot(pre[0]), __ballot(pre[1]), __ballot(pre[2]), __ballot(pre[3])};
+        if ((pm[0] | pm[1] | pm[2] | pm[3]) != 0ull) {
 #pragma unroll
             for (int p = 0; p < 4; p++) {
-                const u64 bal = __ballot(pre[p]);
+                const u64 bal = pm[p];
                 if (bal) {
                     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
@@ -279,10 +294,15 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
                 const int left = p ? byte_of(g2b, p - 1) : byte_of(lw, 3);
                 const int gx = right - left;
                 const int gy = byte_of(g2[C], p) - byte_of(g2[A], p);
-                int ang, mag;
-                grad_code(gx, gy, ang, mag);
-                gp[p] = gradp_pack(ang, mag);
-                gf[p] = (uint32_t)ang | ((uint32_t)mag << 16);            // Grad_t {angGrad, magGrad}
+                if constexpr (FULLGRAD) {
+                    int ang, mag;
+                    grad_code(gx, gy, ang, mag);
+                    gp[p] = gradp_pack(ang, mag);
+                    gf[p] = (uint32_t)ang | ((uint32_t)mag << 16);        // Grad_t {angGrad, magGrad}
+                } else {
+                    gp[p] = grad_word(gx, gy);
+                    gf[p] = 0;
+                }
             }
             if constexpr (FULLGRAD)
                 *reinterpret_cast<uint4 *>(gradfull + fpix + (size_t)y * W + (size_t)g * 4) = make_uint4(gf[0], gf[1], gf[2], gf[3]);
