@@ -1,7 +1,8 @@
 // sift_main.cpp -- the reference's host flow (main.cpp:37-210) on this build: read an 8-bit gray
-// frame (binary PGM, or a synthetic frame), time one sift_detect_and_compute call, sort the
+// frame (binary PGM, an 8- or 24-bit BMP like the reference's Data/Bot/bot_N.bmp, or a synthetic
+// frame), time one sift_detect_and_compute call, sort the
 // keypoints by contrast, keep MAX_FINAL_KEYPOINTS, write keypoints and descriptors as text.
-//   sift_main <in.pgm | synth:W:H:seed> [out_prefix] [contrastTh=15]
+//   sift_main <in.pgm | in.bmp | synth:W:H:seed> [out_prefix] [contrastTh=15]
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -14,7 +15,40 @@
 
 static uint32_t h32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
 
-static bool load(const char *arg, std::vector<uint8_t> &img, int &W, int &H)
+// Uncompressed BMP, 8 bits (palette) or 24 bits per pixel.  8-bit frames are converted here through
+// the palette; 24-bit frames keep their BGR rows in `bgr` (pitch, bottom-up flag) and are converted on
+// the device by sift_gray_from_bgr once the frame size is known.
+static uint32_t rd32(const uint8_t *p) { return p[0] | p[1] << 8 | p[2] << 16 | (uint32_t)p[3] << 24; }
+static bool load_bmp(FILE *f, std::vector<uint8_t> &img, std::vector<uint8_t> &bgr, long &pitch, int &bottom_up, int &W, int &H)
+{
+    uint8_t h[54];
+    if (fread(h, 1, 54, f) != 54 || h[0] != 'B' || h[1] != 'M') return false;
+    const uint32_t off = rd32(h + 10), hdr = rd32(h + 14), comp = rd32(h + 30);
+    const int w = (int)rd32(h + 18), hh = (int)rd32(h + 22), bpp = h[28] | h[29] << 8;
+    if (hdr < 40 || comp != 0 || w <= 0 || hh == 0 || (bpp != 8 && bpp != 24)) return false;
+    W = w; H = hh < 0 ? -hh : hh; bottom_up = hh > 0;
+    pitch = ((long)W * (bpp / 8) + 3) / 4 * 4;
+    uint8_t pal[256][4] = {};
+    if (bpp == 8) {
+        uint32_t ncol = rd32(h + 46);
+        if (ncol == 0 || ncol > 256) ncol = 256;
+        if (fseek(f, 14 + (long)hdr, SEEK_SET) != 0 || fread(pal, 4, ncol, f) != ncol) return false;
+    }
+    std::vector<uint8_t> raw((size_t)pitch * H);
+    if (fseek(f, (long)off, SEEK_SET) != 0 || fread(raw.data(), 1, raw.size(), f) != raw.size()) return false;
+    if (bpp == 24) { bgr.swap(raw); return true; }
+    img.resize((size_t)W * H);
+    for (int y = 0; y < H; y++) {
+        const uint8_t *row = raw.data() + (size_t)(bottom_up ? H - 1 - y : y) * pitch;
+        for (int x = 0; x < W; x++) {
+            const uint8_t *c = pal[row[x]];                        // B, G, R, reserved
+            img[(size_t)y * W + x] = (uint8_t)((c[0] * 1868 + c[1] * 9617 + c[2] * 4899 + 8192) >> 14);
+        }
+    }
+    return true;
+}
+
+static bool load(const char *arg, std::vector<uint8_t> &img, std::vector<uint8_t> &bgr, long &pitch, int &bottom_up, int &W, int &H)
 {
     unsigned w, h, seed;
     if (sscanf(arg, "synth:%u:%u:%u", &w, &h, &seed) == 3) {       // SURVEY.md 8(d) generator
@@ -31,6 +65,12 @@ static bool load(const char *arg, std::vector<uint8_t> &img, int &W, int &H)
     }
     FILE *f = fopen(arg, "rb");
     if (!f) return false;
+    const size_t n = strlen(arg);
+    if (n > 4 && (!strcmp(arg + n - 4, ".bmp") || !strcmp(arg + n - 4, ".BMP"))) {
+        const bool ok = load_bmp(f, img, bgr, pitch, bottom_up, W, H);
+        fclose(f);
+        return ok;
+    }
     char magic[3] = {0};
     int maxv = 0;
     bool ok = fscanf(f, "%2s %d %d %d", magic, &W, &H, &maxv) == 4 && !strcmp(magic, "P5") && maxv == 255;
@@ -46,9 +86,11 @@ static bool load(const char *arg, std::vector<uint8_t> &img, int &W, int &H)
 int main(int argc, char **argv)
 {
     if (argc < 2) { fprintf(stderr, "usage: %s <in.pgm | synth:W:H:seed> [out_prefix] [contrastTh]\n", argv[0]); return 2; }
-    std::vector<uint8_t> img;
-    int W = 0, H = 0;
-    if (!load(argv[1], img, W, H)) { fprintf(stderr, "cannot read %s\n", argv[1]); return 1; }
+    std::vector<uint8_t> img, bgr;
+    long pitch = 0;
+    int W = 0, H = 0, bottom_up = 0;
+    if (!load(argv[1], img, bgr, pitch, bottom_up, W, H)) { fprintf(stderr, "cannot read %s\n", argv[1]); return 1; }
+    if (W % 4) { fprintf(stderr, "frame width must be a multiple of 4\n"); return 1; }
     const int th = argc > 3 ? atoi(argv[3]) : 15;                  // main.cpp:73
     sift_set_frame_size(W, H);
 
@@ -56,7 +98,8 @@ int main(int argc, char **argv)
     Keypoint_t *kps = (Keypoint_t *)sift_alloc(MAX_KEYPOINTS * sizeof(Keypoint_t));
     Desc_t *desc = (Desc_t *)sift_alloc((size_t)MAX_KEYPOINTS * DESC_SIZE * sizeof(Desc_t));
     if (!src || !kps || !desc) { fprintf(stderr, "pinned allocation failed\n"); return 1; }
-    memcpy(src, img.data(), img.size());                           // main.cpp:55-58
+    if (!bgr.empty()) sift_gray_from_bgr(bgr.data(), pitch, bottom_up, src);   // main.cpp:51: colour file read as gray
+    else memcpy(src, img.data(), img.size());                      // main.cpp:55-58
 
     sift_detect_and_compute(src, kps, desc, th);                   // warm-up: creates the context
     auto t0 = std::chrono::steady_clock::now();                    // main.cpp:63-77

@@ -26,3 +26,7 @@ void sift_free(void *p);
 // final keypoint in pKeypoints / pDesc.  Returns nKp, the number with x > 0 && y > 0 (:112-129).
 // pKeypoints itself is left as it is (the reference sorts it in place and never reads it again).
 int sift_select_final_keypoints(const Keypoint_t *pKeypoints, Keypoint_t *pFinalKeypoints, uint32_t *pSlot);
+// The ingest step of main.cpp:51-58 for a colour frame: 24-bit BGR rows (`pitch` bytes apart, a multiple
+// of 4; bottomUp != 0 for BMP's row order) to WIDTH x HEIGHT gray bytes on the device, with the weights
+// of cv::imread(..., CV_LOAD_IMAGE_GRAYSCALE).
+void sift_gray_from_bgr(const uint8_t *pBgr, long pitch, int bottomUp, Pixel_t *pGray);

@@ -123,6 +123,13 @@ int sift_hip_batch_top(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const
                        sift_keypoint *final_kps, uint32_t *final_index, uint32_t *final_desc, uint32_t *nvalid,
                        int contrastTh);
 
+/* The ingest step of main.cpp:51-58 for colour frames: 24-bit BGR rows (as in a BMP: `pitch` bytes
+ * apart, a multiple of 4, 0 = 3*width; bottom_up != 0 when the first stored row is the bottom one)
+ * to the width*height gray bytes the entry points above take, with the fixed-point weights of
+ * cv::imread(..., CV_LOAD_IMAGE_GRAYSCALE): gray = (1868 B + 9617 G + 4899 R + 8192) >> 14.
+ * OpenCV is not part of the reference tree: the formula is restated from its published source. */
+int sift_hip_gray_from_bgr(sift_hip_ctx *ctx, const uint8_t *bgr, long pitch, int bottom_up, uint8_t *gray);
+
 /* ---- device-buffer entry points ------------------------------------------
  * Same work with inputs and outputs already resident in this context's device
  * memory (what the SDSoC data movers of DetectKeypoints.cpp:1054-1069 would
@@ -155,6 +162,11 @@ int sift_hip_descriptor_dev(sift_hip_ctx *ctx, const sift_grad *d_grad, int nfra
 int sift_hip_select_top_dev(sift_hip_ctx *ctx, const sift_keypoint *d_kps, int nframes, int nfinal,
                             sift_keypoint *d_final, uint32_t *d_index, uint32_t *d_nvalid, const uint32_t *d_desc,
                             uint32_t *d_final_desc, void *stream);
+
+/* sift_hip_gray_from_bgr on device buffers: d_bgr nframes*height*pitch bytes (4-byte aligned) ->
+ * d_gray nframes*width*height, e.g. straight into the d_imgs of the calls above. */
+int sift_hip_gray_from_bgr_dev(sift_hip_ctx *ctx, const uint8_t *d_bgr, int nframes, long pitch, int bottom_up,
+                               uint8_t *d_gray, void *stream);
 
 /* Block until everything this context enqueued has finished. */
 int sift_hip_sync(sift_hip_ctx *ctx);

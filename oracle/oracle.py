@@ -164,3 +164,14 @@ def select_top(kps, nfinal=1000):
     f.restype = C.c_int
     nvalid = f(_p(kps), C.c_int(len(kps)), C.c_int(nfinal), _p(final), _p(index))
     return final, index, nvalid
+
+
+def bgr2gray(bgr, W, bottom_up=False):
+    """main.cpp:51-58 for a colour frame: bgr [H, pitch] uint8 -> gray [H, W] (OpenCV's fixed-point weights)."""
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    if bgr.ndim == 3:
+        bgr = bgr.reshape(bgr.shape[0], -1)
+    H, pitch = bgr.shape
+    gray = np.zeros((H, W), np.uint8)
+    lib().orc_bgr2gray(_p(bgr), C.c_int(W), C.c_int(H), C.c_long(pitch), C.c_int(int(bool(bottom_up))), _p(gray))
+    return gray

@@ -478,3 +478,16 @@ int orc_select_top(const orc_keypoint *kps, int n, int nfinal, orc_keypoint *fin
     free(k);
     return nvalid;
 }
+
+/* ---- ingest of main.cpp:51-58 for colour frames ---------------------------------------------
+ * cv::imread(path, CV_LOAD_IMAGE_GRAYSCALE) on a 24-bit BMP: OpenCV (not in the reference tree, not
+ * installed here; imgcodecs utils.cpp, icvCvt_BGR2Gray_8u_C3C1R) uses cR = 4899, cG = 9617,
+ * cB = 16384 - cR - cG = 1868 and descale(x, 14) = (x + 8192) >> 14.  Unpinned restatement. */
+void orc_bgr2gray(const uint8_t *bgr, int W, int H, long pitch, int bottom_up, uint8_t *gray)
+{
+    for (int y = 0; y < H; y++) {
+        const uint8_t *row = bgr + (size_t)(bottom_up ? H - 1 - y : y) * (size_t)pitch;
+        for (int x = 0; x < W; x++)
+            gray[(size_t)y * W + x] = (uint8_t)((row[3 * x] * 1868 + row[3 * x + 1] * 9617 + row[3 * x + 2] * 4899 + 8192) >> 14);
+    }
+}

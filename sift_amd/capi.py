@@ -26,7 +26,7 @@ EXPORTS = (
     "sift_hip_create", "sift_hip_destroy", "sift_hip_last_error", "sift_hip_device_count",
     "sift_hip_host_alloc", "sift_hip_host_free",
     "sift_hip_detect_and_compute", "sift_hip_detect", "sift_hip_main_orientation", "sift_hip_descriptor",
-    "sift_hip_select_top", "sift_hip_select_top_dev",
+    "sift_hip_select_top", "sift_hip_select_top_dev", "sift_hip_gray_from_bgr", "sift_hip_gray_from_bgr_dev",
     "sift_hip_batch", "sift_hip_batch_top", "sift_hip_detect_and_compute_dev", "sift_hip_detect_dev",
     "sift_hip_main_orientation_dev", "sift_hip_descriptor_dev", "sift_hip_sync", "sift_hip_debug_planes",
     "sift_hip_set_profiling", "sift_hip_stage_ms", "sift_hip_stage_name", "sift_hip_set_blur_rows", "sift_hip_set_detect_rows",
@@ -86,6 +86,8 @@ def load_library():
     lib.sift_hip_descriptor_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     lib.sift_hip_select_top.argtypes = [vp, vp, i32, vp, vp, C.POINTER(C.c_uint32)]
     lib.sift_hip_select_top_dev.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.sift_hip_gray_from_bgr.argtypes = [vp, vp, C.c_long, i32, vp]
+    lib.sift_hip_gray_from_bgr_dev.argtypes = [vp, vp, i32, C.c_long, i32, vp, vp]
     lib.sift_hip_sync.argtypes = [vp]
     lib.sift_hip_debug_planes.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     lib.sift_hip_set_profiling.argtypes = [vp, i32]

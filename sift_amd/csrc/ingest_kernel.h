@@ -1,0 +1,39 @@
+// ingest_kernel.h -- colour frame -> 8-bit gray on the device (the ingest step of main.cpp:51-58).
+//
+// The reference reads every frame with cv::imread(path, CV_LOAD_IMAGE_GRAYSCALE) (main.cpp:51) and
+// copies the gray bytes into the hardware buffer (:55-58).  For a 24-bit BMP OpenCV's reader turns
+// BGR into gray with fixed-point weights (imgcodecs utils.cpp, icvCvt_BGR2Gray_8u_C3C1R, 2.4/3.x):
+//     gray = (B * 1868 + G * 9617 + R * 4899 + 8192) >> 14
+// OpenCV is not part of the reference tree and is not installed here, so this formula is restated
+// from its published source and is unpinned.  Rows may be stored bottom-up (BMP) and padded.
+//
+// HBM-bound: 3 bytes read, 1 written per pixel.  A lane converts 4 pixels from three aligned dwords.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sift {
+
+__device__ __forceinline__ uint32_t bgr_gray(uint32_t b, uint32_t g, uint32_t r)
+{
+    return (b * 1868u + g * 9617u + r * 4899u + 8192u) >> 14;
+}
+
+// grid: x = ceil(W/4 / 256), y = rows, z = frames; block = 256.  src: frames of `rows` x src_pitch
+// bytes (pitch a multiple of 4, >= 3*W); flip: source row H-1-y feeds output row y (bottom-up files).
+__global__ __launch_bounds__(256) void k_bgr2gray(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int W, int H,
+                                                  long src_pitch, long src_frame, int flip)
+{
+    const int xq = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (xq >= (W >> 2)) return;
+    const int sy = flip ? H - 1 - y : y;
+    const uint32_t *__restrict__ p = reinterpret_cast<const uint32_t *>(src + (size_t)blockIdx.z * src_frame + (size_t)sy * src_pitch) + (size_t)xq * 3;
+    const uint32_t a = p[0], b = p[1], c = p[2];      // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+    const uint32_t g0 = bgr_gray(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u);
+    const uint32_t g1 = bgr_gray(a >> 24, b & 255u, (b >> 8) & 255u);
+    const uint32_t g2 = bgr_gray((b >> 16) & 255u, b >> 24, c & 255u);
+    const uint32_t g3 = bgr_gray((c >> 8) & 255u, (c >> 16) & 255u, c >> 24);
+    reinterpret_cast<uint32_t *>(dst + ((size_t)blockIdx.z * H + y) * W)[xq] = g0 | g1 << 8 | g2 << 16 | g3 << 24;
+}
+
+}  // namespace sift

@@ -22,6 +22,7 @@
 #include "compact_kernel.h"
 #include "describe_kernel.h"
 #include "select_kernel.h"
+#include "ingest_kernel.h"
 
 static_assert(sizeof(sift_keypoint) == 8 && sizeof(sift::kp_t) == 8, "Keypoint_t is 8 bytes");
 static_assert(sizeof(sift_grad) == 4, "Grad_t is 4 bytes");
@@ -197,6 +198,8 @@ struct sift_hip_ctx {
     sift::kp_t *d_tfinal = nullptr;       // sift_hip_batch_top: selected keypoints of the chunks in flight (lazily allocated)
     uint32_t *d_tindex = nullptr, *d_tdesc = nullptr, *d_tnvalid = nullptr;
     size_t top_cap = 0;
+    uint8_t *d_bgr = nullptr;             // staging of sift_hip_gray_from_bgr (lazily allocated)
+    size_t bgr_cap = 0;
     uint2 *d_tab = nullptr;
     uint32_t *d_qtab = nullptr;           // quad table (build_quad_table)
     int ntab = 0, n2 = 0, n2pad = 0, qa = 0, qb = 0;
@@ -473,7 +476,7 @@ void sift_hip_destroy(sift_hip_ctx *c)
     DevGuard g(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_img, c->d_pyr, c->d_zero, c->d_list, c->d_listcount, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_gradp,
-                    c->d_gradfull, c->d_final, c->d_findex, c->d_nvalid, c->d_tfinal, c->d_tindex, c->d_tdesc, c->d_tnvalid, c->d_kps, c->d_desc, c->d_total, c->d_total_ctx, c->d_ori, c->d_tab, c->d_qtab};
+                    c->d_gradfull, c->d_final, c->d_findex, c->d_nvalid, c->d_tfinal, c->d_tindex, c->d_tdesc, c->d_tnvalid, c->d_bgr, c->d_kps, c->d_desc, c->d_total, c->d_total_ctx, c->d_ori, c->d_tab, c->d_qtab};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &ps : c->prof)
         for (int i = 0; i < SIFT_HIP_NSTAGES; i++)
@@ -616,7 +619,47 @@ int sift_hip_select_top_dev(sift_hip_ctx *c, const sift_keypoint *d_kps, int nfr
     return SIFT_HIP_OK;
 }
 
+int sift_hip_gray_from_bgr_dev(sift_hip_ctx *c, const uint8_t *d_bgr, int nframes, long pitch, int bottom_up,
+                               uint8_t *d_gray, void *stream)
+{
+    if (int r = check_ctx(c)) return r;
+    if (!d_bgr || !d_gray) return fail(SIFT_HIP_EINVAL, "null buffer");
+    if (nframes < 1) return fail(SIFT_HIP_EINVAL, "nframes must be >= 1");
+    if (pitch == 0) pitch = 3L * c->W;
+    if (pitch < 3L * c->W || (pitch & 3)) return fail(SIFT_HIP_EINVAL, "pitch must be a multiple of 4 and >= 3 * width");
+    if ((uintptr_t)d_bgr & 3) return fail(SIFT_HIP_EINVAL, "d_bgr must be 4-byte aligned");
+    DevGuard g(c->device);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    dim3 grid((c->W / 4 + 255) / 256, c->H, nframes);
+    hipLaunchKernelGGL(sift::k_bgr2gray, grid, dim3(256), 0, s, d_bgr, d_gray, c->W, c->H, pitch, pitch * c->H,
+                       bottom_up ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return SIFT_HIP_OK;
+}
+
 /* ---- host-buffer entry points ------------------------------------------ */
+
+int sift_hip_gray_from_bgr(sift_hip_ctx *c, const uint8_t *bgr, long pitch, int bottom_up, uint8_t *gray)
+{
+    if (int r = check_ctx(c)) return r;
+    if (!bgr || !gray) return fail(SIFT_HIP_EINVAL, "null buffer");
+    if (pitch == 0) pitch = 3L * c->W;
+    if (pitch < 3L * c->W || (pitch & 3)) return fail(SIFT_HIP_EINVAL, "pitch must be a multiple of 4 and >= 3 * width");
+    DevGuard g(c->device);
+    hipStream_t s = c->stream;
+    const size_t bytes = (size_t)pitch * c->H;
+    if (c->bgr_cap < bytes) {
+        if (c->d_bgr) (void)hipFree(c->d_bgr);
+        c->d_bgr = nullptr; c->bgr_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_bgr, bytes));
+        c->bgr_cap = bytes;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_bgr, bgr, bytes, hipMemcpyHostToDevice, s));
+    if (int r = sift_hip_gray_from_bgr_dev(c, c->d_bgr, 1, pitch, bottom_up, c->d_img, s)) return r;
+    HIP_TRY(hipMemcpyAsync(gray, c->d_img, c->npix, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SIFT_HIP_OK;
+}
 
 int sift_hip_select_top(sift_hip_ctx *c, const sift_keypoint *kps, int nfinal, sift_keypoint *final_kps, uint32_t *index,
                         uint32_t *nvalid)

@@ -71,6 +71,12 @@ void sift_detect_and_compute(Pixel_t *pSrcImageCam0, Keypoint_t *pKeypoints, Des
         die("sift_detect_and_compute");
 }
 
+void sift_gray_from_bgr(const uint8_t *pBgr, long pitch, int bottomUp, Pixel_t *pGray)
+{
+    std::lock_guard<std::mutex> l(g_mu);
+    if (sift_hip_gray_from_bgr(ctx(), pBgr, pitch, bottomUp, pGray) != SIFT_HIP_OK) die("sift_gray_from_bgr");
+}
+
 int sift_select_final_keypoints(const Keypoint_t *pKeypoints, Keypoint_t *pFinalKeypoints, uint32_t *pSlot)
 {
     std::lock_guard<std::mutex> l(g_mu);

@@ -106,6 +106,21 @@ class SiftContext:
         check(self._lib.sift_hip_descriptor(self._h, _vp(grad), _vp(kps), _vp(ori), _vp(desc)))
         return desc
 
+    def gray_from_bgr(self, bgr, bottom_up=False):
+        """main.cpp:51-58 for a colour frame: bgr [H, pitch] uint8 rows (pitch >= 3*W, multiple of 4) -> gray [H, W]"""
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        if bgr.ndim == 3:
+            bgr = bgr.reshape(bgr.shape[0], -1)
+        if bgr.shape[0] != self.height:
+            raise ValueError("frame must have %d rows" % self.height)
+        gray = np.empty((self.height, self.width), np.uint8)
+        check(self._lib.sift_hip_gray_from_bgr(self._h, _vp(bgr), int(bgr.shape[1]), int(bool(bottom_up)), _vp(gray)))
+        return gray
+
+    def gray_from_bgr_dev(self, d_bgr, nframes, pitch, bottom_up, d_gray, stream=None):
+        check(self._lib.sift_hip_gray_from_bgr_dev(self._h, _dp(d_bgr), int(nframes), int(pitch), int(bool(bottom_up)),
+                                                   _dp(d_gray), _dp(stream)))
+
     def select_top(self, kps, nfinal=MAX_FINAL_KEYPOINTS):
         """main.cpp:82-130 -> (pFinalKeypoints[nfinal], slot index[nfinal], nKp); equal contrasts keep slot order"""
         kps = self._kps(kps)

@@ -79,3 +79,28 @@ def test_main_like_driver(tmp_path, orc):
     assert sorted(idx.tolist()) == list(range(985))
     assert (got[:, 1] == rk["x"][idx]).all() and (got[:, 2] == rk["y"][idx]).all()
     assert (gd == rd[idx]).all()
+
+
+@pytest.mark.gpu
+def test_main_like_driver_reads_bmp(tmp_path, orc):
+    """main.cpp:41-58: frames come as .bmp files read as gray; 8-bit (palette) and 24-bit files."""
+    from PIL import Image
+    W, H = 640, 480
+    gray = orc.synth_frame(1, W, H)
+    Image.fromarray(gray).save(tmp_path / "g8.bmp")                          # 8-bit, gray palette
+    rng = np.random.default_rng(4)
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "c24.bmp")                          # 24-bit, stored B, G, R bottom-up
+    expect = {"g8": gray, "c24": orc.bgr2gray(rgb[..., ::-1].copy(), W)}
+    for name, img in expect.items():
+        out = subprocess.run([MAIN, str(tmp_path / (name + ".bmp")), str(tmp_path / name)], capture_output=True, text=True,
+                             timeout=120)
+        assert out.returncode == 0, out.stdout + out.stderr
+        rk, rd, _ = orc.detect_and_compute(img)
+        n = int((rk["contrast"] > 0).sum())
+        assert ("%d keypoints" % n) in out.stdout
+        if n:
+            got = np.loadtxt(tmp_path / (name + "_keypoints.txt"), dtype=np.int64, ndmin=2)
+            idx = got[:, 0]
+            assert len(idx) == min(n, 1000)
+            assert (got[:, 1] == rk["x"][idx]).all() and (got[:, 2] == rk["y"][idx]).all()
