@@ -48,7 +48,8 @@
     X(34, "v_sad_u32 %0, %1, %2, %0") \
     X(35, "v_dot4_u32_u8 %0, %1, %2, %0\n\tv_add_u32 %0, %1, %0") \
     X(36, "v_dot4_u32_u8 %0, %1, %2, %0\n\tv_dot4_u32_u8 %0, %1, %2, %0\n\tv_dot4_u32_u8 %0, %1, %2, %0\n\tv_add_u32 %0, %1, %0") \
-    X(37, "v_add_u32 %0, %1, %0\n\tv_lshlrev_b32 %0, 1, %0")
+    X(37, "v_add_u32 %0, %1, %0\n\tv_lshlrev_b32 %0, 1, %0") \
+    X(38, "; v_lshl_add_u64 (two 32-bit adds in one)")
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed)
@@ -60,10 +61,11 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed)
     for (int it = 0; it < ITERS; it++) {
 #pragma unroll
         for (int i = 0; i < ACC; i++) {
-#define X(n, s) if (OP == n && n != 22) asm volatile(s : "+v"(a[i]) : "v"(x), "v"(y) : "vcc");
+#define X(n, s) if (OP == n && n != 22 && n != 38) asm volatile(s : "+v"(a[i]) : "v"(x), "v"(y) : "vcc");
             OPS(X)
 #undef X
             if (OP == 22) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a2[i]) : "v"(x2), "v"(y2));
+            if (OP == 38) asm volatile("v_lshl_add_u64 %0, %1, 0, %0" : "+v"(a2[i]) : "v"(x2));
         }
     }
     uint32_t s = 0;
