@@ -150,6 +150,16 @@ __device__ __forceinline__ void slide(uint32_t (&a)[ksize<WHICH>()][4], const ui
 // folded) and added to both with plain adds, which issue at twice the rate of a dot4.  The slots
 // are still updated in ascending order (slot s takes the old slot s+1), so the contributions of
 // the lower half stay in registers until the upper half has used them.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// two dwords as one 64-bit value: a register pair, no instruction (as a shift-and-or it costs moves)
+__device__ __forceinline__ uint64_t pair64(uint32_t lo, uint32_t hi)
+{
+    u32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint64_t, v);
+}
+__device__ __forceinline__ uint32_t lo32(uint64_t v) { return __builtin_bit_cast(u32x2, v).x; }
+__device__ __forceinline__ uint32_t hi32(uint64_t v) { return __builtin_bit_cast(u32x2, v).y; }
+
 template <int WHICH, int R>
 __device__ __forceinline__ void row_contrib(uint32_t (&c)[4], const uint32_t (&w)[4][5], const uint32_t (&init)[4])
 {
@@ -173,8 +183,11 @@ __device__ __forceinline__ void row_contrib(uint32_t (&c)[4], const uint32_t (&w
                 for (int p = 0; p < 4; p++) h[p] = __builtin_amdgcn_udot4(w[p][j], k, h[p], false);
             }
         });
-#pragma unroll
-        for (int p = 0; p < 4; p++) c[p] = (h[p] << 8) + c[p];
+        // (h << 8) + c for two pixels at once: h < 2^16, so the shift does not cross the dwords
+        const uint64_t r0 = (pair64(h[0], h[1]) << 8) + pair64(c[0], c[1]);
+        const uint64_t r1 = (pair64(h[2], h[3]) << 8) + pair64(c[2], c[3]);
+        c[0] = lo32(r0); c[1] = hi32(r0);
+        c[2] = lo32(r1); c[3] = hi32(r1);
     }
 }
 
@@ -189,32 +202,45 @@ constexpr bool table_is_symmetric()
     return true;
 }
 
+// Two accumulators per 64-bit add: an accumulator stays below 2^24 (255 * 32765 + 16384), so adding
+// the pixel pairs (0,1) and (2,3) as 64-bit values never carries from the low dword into the high
+// one, and v_lshl_add_u64 issues at the rate of one 32-bit add (tools/ubench/valu_rate.hip).
+// Two accumulators per 64-bit add: an accumulator stays below 2^24 (255 * 32765 + 16384), so adding
+// the pixel pairs (0,1) and (2,3) as 64-bit values never carries from the low dword into the high
+// one, and v_lshl_add_u64 issues at the rate of one 32-bit add (tools/ubench/valu_rate.hip).  The
+// state of this variant is therefore held as pairs: a[slot][0] = pixels 0|1, a[slot][1] = pixels 2|3.
 template <int WHICH>
-__device__ __forceinline__ void slide_sym(uint32_t (&a)[ksize<WHICH>()][4], const uint32_t (&w)[4][5])
+__device__ __forceinline__ void slide_sym(uint64_t (&a)[ksize<WHICH>()][2], const uint32_t (&w)[4][5])
 {
     constexpr int N = ksize<WHICH>(), C = N / 2;
     static_assert(table_is_symmetric<WHICH>(), "rows R and N-1-R must be equal");
     const uint32_t zero[4] = {0, 0, 0, 0};
-    uint32_t c[C][4];
+    uint64_t c[C][2];
     // slots 0..C-1 (table rows N-1-s = rows s)
     static_for<0, C>([&](auto ss) {
         constexpr int s = ss;
-        row_contrib<WHICH, s>(c[s], w, zero);
-#pragma unroll
-        for (int p = 0; p < 4; p++) a[s][p] = a[s + 1][p] + c[s][p];
+        uint32_t t[4];
+        row_contrib<WHICH, s>(t, w, zero);
+        c[s][0] = pair64(t[0], t[1]);
+        c[s][1] = pair64(t[2], t[3]);
+        a[s][0] = a[s + 1][0] + c[s][0];
+        a[s][1] = a[s + 1][1] + c[s][1];
     });
     // the centre row has no partner: the chain starts from the old slot C+1
     {
+        const uint32_t init[4] = {lo32(a[C + 1][0]), hi32(a[C + 1][0]), lo32(a[C + 1][1]), hi32(a[C + 1][1])};
         uint32_t t[4];
-        row_contrib<WHICH, C>(t, w, a[C + 1]);
-#pragma unroll
-        for (int p = 0; p < 4; p++) a[C][p] = t[p];
+        row_contrib<WHICH, C>(t, w, init);
+        a[C][0] = pair64(t[0], t[1]);
+        a[C][1] = pair64(t[2], t[3]);
     }
     // slots C+1..N-1 (table rows N-1-s) reuse the contribution of slot N-1-s
     static_for<C + 1, N>([&](auto ss) {
         constexpr int s = ss;
-#pragma unroll
-        for (int p = 0; p < 4; p++) a[s][p] = (s == N - 1 ? BLUR_INIT : a[s + 1 < N ? s + 1 : s][p]) + c[N - 1 - s][p];
+        constexpr int nx = s + 1 < N ? s + 1 : s;
+        const uint64_t init = pair64(BLUR_INIT, BLUR_INIT);
+        a[s][0] = (s == N - 1 ? init : a[nx][0]) + c[N - 1 - s][0];
+        a[s][1] = (s == N - 1 ? init : a[nx][1]) + c[N - 1 - s][1];
     });
 }
 
@@ -224,6 +250,12 @@ __device__ __forceinline__ uint32_t pack4_q15(const uint32_t (&a)[4])
     uint32_t lo = (a[0] >> 15) | ((a[1] >> 15) << 8);
     uint32_t hi = (a[2] >> 15) | ((a[3] >> 15) << 8);
     return lo | (hi << 16);
+}
+
+__device__ __forceinline__ uint32_t pack4_q15(const uint64_t (&a)[2])
+{
+    const uint32_t t[4] = {lo32(a[0]), hi32(a[0]), lo32(a[1]), hi32(a[1])};
+    return pack4_q15(t);
 }
 
 // "pyr" plane: one uint4 per group of 4 pixels = { src, G1, G2, G3 }, each a dword with pixel p
@@ -267,19 +299,22 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, 
         for (int k = 0; k < 7; k++) A[k] = *reinterpret_cast<const uint32_t *>(rp + qc[k]);
     };
 
-    uint32_t a3[19][4], a2[11][4], a1[5][4];
+    // per slot 4 x u32 (GUARD) or 2 x u64 (pixel pairs, see slide_sym)
+    constexpr int NP = GUARD ? 4 : 2;
+    using acc_t = std::conditional_t<GUARD, uint32_t, uint64_t>;
+    acc_t a3[19][NP], a2[11][NP], a1[5][NP];
 #pragma unroll
     for (int s = 0; s < 19; s++)
 #pragma unroll
-        for (int p = 0; p < 4; p++) a3[s][p] = 0;
+        for (int p = 0; p < NP; p++) a3[s][p] = 0;
 #pragma unroll
     for (int s = 0; s < 11; s++)
 #pragma unroll
-        for (int p = 0; p < 4; p++) a2[s][p] = 0;
+        for (int p = 0; p < NP; p++) a2[s][p] = 0;
 #pragma unroll
     for (int s = 0; s < 5; s++)
 #pragma unroll
-        for (int p = 0; p < 4; p++) a1[s][p] = 0;
+        for (int p = 0; p < NP; p++) a1[s][p] = 0;
     uint32_t d1[7] = {0, 0, 0, 0, 0, 0, 0}, d2[4] = {0, 0, 0, 0};
 
     uint32_t cur[7], nxt[7];
