@@ -62,6 +62,36 @@ __global__ void kshape(const char *plane, const uint32_t *origins, uint32_t *out
     out[(blockIdx.x * (blockDim.x >> 6) + wave) * 64 + lane] = acc;
 }
 
+// the same window from a split format: 1 byte per pixel in one plane (8-byte pieces = 8 pixels) and
+// 4 bits per pixel in a second one (4-byte pieces = 8 pixels): 1.5 instead of 2 bytes per pixel
+template <int NEAR>
+__global__ void ksplit(const char *plane, const uint32_t *origins, uint32_t *out, int W, int iters)
+{
+    constexpr int PER_ROW = 10, N = 71 * PER_ROW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const char *plane2 = plane + (size_t)1920 * 1080 * 32;            // second plane further on in the buffer
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; it++) {
+        const uint32_t o = origins[(blockIdx.x * iters + it) & 0xffff] >> 1;      // pixel index
+        const char *base = plane + (o & ~7u), *base2 = plane2 + ((o >> 1) & ~3u);
+        if (NEAR) { const int dy = (wave * 5) % NEAR, dx = ((wave * 12) % NEAR) & ~7; base += dy * W + dx; base2 += dy * (W / 2) + dx / 2; }
+        for (int i0 = 0; i0 < N; i0 += 256) {
+            uint32_t v[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                int i = i0 + u * 64 + lane;
+                i = i < N ? i : N - 1;
+                const int r = i / PER_ROW, q = i - r * PER_ROW;
+                uint2 d = *(const uint2 *)(base + (size_t)r * W + q * 8);
+                uint32_t e = *(const uint32_t *)(base2 + (size_t)r * (W / 2) + q * 4);
+                v[u] = d.x ^ d.y ^ e;
+            }
+            acc += v[0] + v[1] + v[2] + v[3];
+        }
+    }
+    out[(blockIdx.x * (blockDim.x >> 6) + wave) * 64 + lane] = acc;
+}
+
 template <int ROWS, int PER_ROW, int PITCHMUL>
 int shape_case(const char *plane, const uint32_t *orig, uint32_t *out, int W, int blocks, int iters)
 {
@@ -104,6 +134,22 @@ int main()
         CHECK(hipMemcpy(orig, o.data(), o.size() * 4, hipMemcpyHostToDevice));
         if (al == 0) {
             if (shape_case<71, 19, 1>(plane, orig, out, W, blocks, iters)) return 1;
+            {
+                hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+                float m1 = 0, m8 = 0;
+                for (int rep = 0; rep < 2; rep++) {
+                    CHECK(hipEventRecord(e0));
+                    ksplit<0><<<blocks, 64>>>(plane, orig, out, W, iters);
+                    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+                    CHECK(hipEventElapsedTime(&m1, e0, e1));
+                    CHECK(hipEventRecord(e0));
+                    ksplit<40><<<blocks / 8, 512>>>(plane, orig, out, W, iters);
+                    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+                    CHECK(hipEventElapsedTime(&m8, e0, e1));
+                }
+                printf("split format (1 B + 4 bit per pixel, 8 + 4 byte pieces): random windows %.1f ns, neighbouring (8 waves/block) %.1f ns per window per CU\n",
+                       m1 * 1e6 / ((double)blocks * iters / 256), m8 * 1e6 / ((double)blocks * iters / 256));
+            }
             if (shape_case<36, 38, 2>(plane, orig, out, W, blocks, iters)) return 1;
             if (shape_case<18, 76, 4>(plane, orig, out, W, blocks, iters)) return 1;
             if (shape_case<9, 152, 8>(plane, orig, out, W, blocks, iters)) return 1;
