@@ -198,6 +198,9 @@ const char *sift_hip_stage_name(int stage);
 
 /* Tuning knob: rows per thread strip of the blur kernel (0 = heuristic). */
 int sift_hip_set_blur_rows(sift_hip_ctx *ctx, int rows);
+/* Tuning knob: sift_hip_detect_and_compute_dev calls of up to `max_frames` frames (default 4) that
+ * repeat the previous call's buffers and parameters are replayed as one HIP graph; 0 = never. */
+int sift_hip_set_graph_frames(sift_hip_ctx *ctx, int max_frames);
 /* Tuning knob: rows per strip of the detect kernel (0 = heuristic; clamped to [4, 32]). */
 int sift_hip_set_detect_rows(sift_hip_ctx *ctx, int rows);
 

@@ -204,6 +204,10 @@ struct sift_hip_ctx {
     uint32_t *d_qtab = nullptr;           // quad table (build_quad_table)
     int ntab = 0, n2 = 0, n2pad = 0, qa = 0, qb = 0;
     int blur_rows = 0;
+    // graph of the last fused call (small batches: launch gaps are a third of a single frame's time)
+    struct GraphKey { const void *imgs = nullptr, *kps = nullptr, *desc = nullptr, *total = nullptr; int nframes = 0, th = 0, brows = 0, drows = 0; } gkey;
+    hipGraphExec_t gexec = nullptr;
+    int graph_max_frames = 4;             // calls with more frames are launched kernel by kernel (0: never use a graph)
     int detect_rows = 0;                  // rows per k_detect strip (0 = heuristic)
     int blur_sym_rows = 48;               // strips at least this long run k_blur<false>
     // profiling: a ring of `nslots` calls, one HIP event pair per kernel of a call
@@ -481,6 +485,7 @@ void sift_hip_destroy(sift_hip_ctx *c)
     for (auto &ps : c->prof)
         for (int i = 0; i < SIFT_HIP_NSTAGES; i++)
             for (int k = 0; k < 2; k++) if (ps.ev[i][k]) hipEventDestroy(ps.ev[i][k]);
+    if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -517,6 +522,14 @@ int sift_hip_set_blur_rows(sift_hip_ctx *c, int rows)
     if (int r = check_ctx(c)) return r;
     if (rows < 0) return fail(SIFT_HIP_EINVAL, "rows must be >= 0");
     c->blur_rows = rows;
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_set_graph_frames(sift_hip_ctx *c, int max_frames)
+{
+    if (int r = check_ctx(c)) return r;
+    if (max_frames < 0) return fail(SIFT_HIP_EINVAL, "max_frames must be >= 0");
+    c->graph_max_frames = max_frames;
     return SIFT_HIP_OK;
 }
 
@@ -569,9 +582,34 @@ int sift_hip_detect_and_compute_dev(sift_hip_ctx *c, const uint8_t *d_imgs, int 
     DevGuard g(c->device);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     begin_call(c);
-    if (int r = run_detect(c, d_imgs, nframes, nullptr, (sift::kp_t *)d_kps, d_total, contrastTh, s)) return r;
-    return run_describe<sift::GRAD_PACKED16, sift::DESC_FUSED>(c, c->d_gradp, nframes, (const sift::kp_t *)d_kps,
-                                                               nullptr, nullptr, d_desc, s);
+    auto enqueue = [&]() -> int {
+        if (int r = run_detect(c, d_imgs, nframes, nullptr, (sift::kp_t *)d_kps, d_total, contrastTh, s)) return r;
+        return run_describe<sift::GRAD_PACKED16, sift::DESC_FUSED>(c, c->d_gradp, nframes, (const sift::kp_t *)d_kps,
+                                                                   nullptr, nullptr, d_desc, s);
+    };
+    // Small batches: the memset and the five kernels are replayed as one graph when the call repeats
+    // the previous one (same buffers, batch and parameters), which takes the launch gaps out.  Not
+    // with profiling on (its events belong to single launches) and not on the legacy default stream.
+    if (c->cur >= 0 || nframes > c->graph_max_frames || s == nullptr) return enqueue();
+    const sift_hip_ctx::GraphKey key = {d_imgs, d_kps, d_desc, d_total, nframes, contrastTh, c->blur_rows, c->detect_rows};
+    const sift_hip_ctx::GraphKey &k = c->gkey;
+    const bool same = c->gexec && k.imgs == key.imgs && k.kps == key.kps && k.desc == key.desc && k.total == key.total &&
+                      k.nframes == key.nframes && k.th == key.th && k.brows == key.brows && k.drows == key.drows;
+    if (!same) {
+        if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return enqueue(); }
+        const int r = enqueue();
+        const hipError_t e = hipStreamEndCapture(s, &graph);
+        if (r) { if (graph) (void)hipGraphDestroy(graph); return r; }
+        if (e != hipSuccess || !graph) return fail(SIFT_HIP_EHIP, "hipStreamEndCapture", e);
+        const hipError_t ei = hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ei != hipSuccess) { c->gexec = nullptr; return fail(SIFT_HIP_EHIP, "hipGraphInstantiate", ei); }
+        c->gkey = key;
+    }
+    HIP_TRY(hipGraphLaunch(c->gexec, s));
+    return SIFT_HIP_OK;
 }
 
 int sift_hip_main_orientation_dev(sift_hip_ctx *c, const sift_grad *d_grad, int nframes, const sift_keypoint *d_kps,

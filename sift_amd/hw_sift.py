@@ -173,6 +173,9 @@ class SiftContext:
     def set_blur_rows(self, rows):
         check(self._lib.sift_hip_set_blur_rows(self._h, int(rows)))
 
+    def set_graph_frames(self, max_frames):
+        check(self._lib.sift_hip_set_graph_frames(self._h, int(max_frames)))
+
     def set_detect_rows(self, rows):
         check(self._lib.sift_hip_set_detect_rows(self._h, int(rows)))
 

@@ -271,3 +271,50 @@ def test_strip_lengths_do_not_change_results(sift, orc):
             grad, kps2 = ctx.sift_detect(img)
             rg = orc.sift_detect(img)["grad"]
             assert (kps2 == rk).all() and (grad["ang"] == rg["ang"]).all() and (grad["mag"] == rg["mag"]).all()
+
+
+def test_graph_replay_of_repeated_small_calls(sift, orc):
+    """Calls of a few frames that repeat the previous call are replayed as one HIP graph: same bits as
+    kernel-by-kernel launches, also after the frame changed in place, after a switch of buffers, with
+    a caller's stream, and with profiling (which bypasses the graph)."""
+    import torch
+    W, H, K = 640, 480, 10000
+    imgs = [orc.synth_frame(s, W, H) for s in (1, 2)]
+    ref = [orc.detect_and_compute(im) for im in imgs]
+    with sift.SiftContext(W, H, max_batch=2) as ctx:
+        d_img = torch.from_numpy(imgs[0]).cuda()
+        bufs = [(torch.zeros((K, 2), dtype=torch.int32, device="cuda"), torch.zeros((K, 72), dtype=torch.int32, device="cuda"))
+                for _ in range(2)]
+
+        def check(kd, which):
+            rk, rd, _ = ref[which]
+            n = nvalid(rk)
+            kps = kd[0].cpu().numpy().view(sift.KP_DTYPE).reshape(K)
+            desc = kd[1].cpu().numpy().view(np.uint32)
+            assert (kps == rk).all() and (desc[:n] == rd[:n]).all() and not desc[n:].any()
+
+        for mode in (4, 0):                                         # graph on (default), off
+            ctx.set_graph_frames(mode)
+            for rep in range(3):                                    # capture, replay, replay
+                d_img.copy_(torch.from_numpy(imgs[rep & 1]))        # same buffer, new frame
+                ctx.detect_and_compute_dev(d_img, 1, *bufs[0])
+                ctx.sync()
+                check(bufs[0], rep & 1)
+            ctx.detect_and_compute_dev(d_img, 1, *bufs[1])          # other output buffers: new graph
+            ctx.sync()
+            check(bufs[1], 0)
+        ctx.set_graph_frames(4)
+        st = torch.cuda.Stream()
+        for rep in range(2):
+            ctx.detect_and_compute_dev(d_img, 1, *bufs[0], stream=st.cuda_stream)
+            st.synchronize()
+            check(bufs[0], 0)
+        ctx.set_profiling(2)
+        ctx.detect_and_compute_dev(d_img, 1, *bufs[0])
+        ctx.sync()
+        check(bufs[0], 0)
+        assert ctx.stage_ms()["k_blur"] > 0
+        # the host-buffer entry point goes through the same path
+        for rep in range(3):
+            kps, desc = ctx.sift_detect_and_compute(imgs[1])
+            assert (kps == ref[1][0]).all()
