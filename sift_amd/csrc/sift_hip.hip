@@ -207,6 +207,7 @@ struct sift_hip_ctx {
     // graph of the last fused call (small batches: launch gaps are a third of a single frame's time)
     struct GraphKey { const void *imgs = nullptr, *kps = nullptr, *desc = nullptr, *total = nullptr; int nframes = 0, th = 0, brows = 0, drows = 0; } gkey;
     hipGraphExec_t gexec = nullptr;
+    int gseen = 0;                        // consecutive calls of the shape in gkey
     int graph_max_frames = 4;             // calls with more frames are launched kernel by kernel (0: never use a graph)
     int detect_rows = 0;                  // rows per k_detect strip (0 = heuristic)
     int blur_sym_rows = 48;               // strips at least this long run k_blur<false>
@@ -463,6 +464,7 @@ int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int m
     A((void **)&c->d_tab, tab.size() * sizeof(uint2));
     c->ntab = (int)tab.size(); c->n2 = wt.n2; c->n2pad = wt.n2pad;
     c->qa = qt.qa; c->qb = qt.qb;
+    if (const char *v = getenv("SIFT_HIP_GRAPH_FRAMES")) c->graph_max_frames = std::max(0, atoi(v));   // tuning knob
     A((void **)&c->d_qtab, qt.words.size() * 4);
     if (e == hipSuccess) e = hipMemcpy(c->d_qtab, qt.words.data(), qt.words.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_tab, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice);
@@ -593,10 +595,18 @@ int sift_hip_detect_and_compute_dev(sift_hip_ctx *c, const uint8_t *d_imgs, int 
     if (c->cur >= 0 || nframes > c->graph_max_frames || s == nullptr) return enqueue();
     const sift_hip_ctx::GraphKey key = {d_imgs, d_kps, d_desc, d_total, nframes, contrastTh, c->blur_rows, c->detect_rows};
     const sift_hip_ctx::GraphKey &k = c->gkey;
-    const bool same = c->gexec && k.imgs == key.imgs && k.kps == key.kps && k.desc == key.desc && k.total == key.total &&
+    const bool same = k.imgs == key.imgs && k.kps == key.kps && k.desc == key.desc && k.total == key.total &&
                       k.nframes == key.nframes && k.th == key.th && k.brows == key.brows && k.drows == key.drows;
     if (!same) {
+        // a new call shape: plain launches; the graph is built when the shape has come three times in a
+        // row (building and first launching a graph can cost milliseconds, a one-off call must not pay that)
         if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+        c->gkey = key;
+        c->gseen = 1;
+        return enqueue();
+    }
+    if (!c->gexec) {
+        if (++c->gseen < 3) return enqueue();
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return enqueue(); }
         const int r = enqueue();
@@ -606,7 +616,7 @@ int sift_hip_detect_and_compute_dev(sift_hip_ctx *c, const uint8_t *d_imgs, int 
         const hipError_t ei = hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         if (ei != hipSuccess) { c->gexec = nullptr; return fail(SIFT_HIP_EHIP, "hipGraphInstantiate", ei); }
-        c->gkey = key;
+        (void)hipGraphUpload(c->gexec, s);      // otherwise the first replay pays for it
     }
     HIP_TRY(hipGraphLaunch(c->gexec, s));
     return SIFT_HIP_OK;

@@ -295,17 +295,18 @@ def test_graph_replay_of_repeated_small_calls(sift, orc):
 
         for mode in (4, 0):                                         # graph on (default), off
             ctx.set_graph_frames(mode)
-            for rep in range(3):                                    # capture, replay, replay
+            for rep in range(6):                                    # plain, plain, graph built, replays
                 d_img.copy_(torch.from_numpy(imgs[rep & 1]))        # same buffer, new frame
                 ctx.detect_and_compute_dev(d_img, 1, *bufs[0])
                 ctx.sync()
                 check(bufs[0], rep & 1)
             ctx.detect_and_compute_dev(d_img, 1, *bufs[1])          # other output buffers: new graph
             ctx.sync()
-            check(bufs[1], 0)
+            check(bufs[1], 1)                                       # the frame of the last repetition
         ctx.set_graph_frames(4)
+        d_img.copy_(torch.from_numpy(imgs[0]))
         st = torch.cuda.Stream()
-        for rep in range(2):
+        for rep in range(5):
             ctx.detect_and_compute_dev(d_img, 1, *bufs[0], stream=st.cuda_stream)
             st.synchronize()
             check(bufs[0], 0)
@@ -315,6 +316,6 @@ def test_graph_replay_of_repeated_small_calls(sift, orc):
         check(bufs[0], 0)
         assert ctx.stage_ms()["k_blur"] > 0
         # the host-buffer entry point goes through the same path
-        for rep in range(3):
+        for rep in range(5):
             kps, desc = ctx.sift_detect_and_compute(imgs[1])
             assert (kps == ref[1][0]).all()
