@@ -132,26 +132,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
 
     const long npix = (long)W * H;
     const long origin = (long)(py - 35) * W + (px - 35);
+    const int W4 = W >> 2;
     const char *__restrict__ gplane = reinterpret_cast<const char *>(gradv) +
-                                      ((size_t)blockIdx.y * (size_t)npix) * (PACK ? 2 : 4);
+                                      (size_t)blockIdx.y * (PACK ? gradp_frame_words(W, H) * 2 : (size_t)npix * 4);
     const uint32_t col4 = (uint32_t)(lane & 31) * 4u;
     char *const hbase = reinterpret_cast<char *>(&hist[0][0]);
 
-    // fast path: every window pixel lies in the plane, so a gather is base(SGPR) + 32-bit offset
-    const char *__restrict__ gwin = gplane + origin * (PACK ? 2 : 4);
+    // pixel sweep.  Unchecked (Grad_t planes only): every window pixel lies in the plane, so a gather
+    // is base(SGPR) + 32-bit offset.  The internal plane is read pixel by pixel only for windows the
+    // quad sweep cannot take (none that sift_detect emits), through its interleaved addressing.
+    const char *__restrict__ gwin = gplane + origin * 4;
     auto gather = [&](auto chk, uint32_t off2, bool live) -> uint32_t {
         if constexpr (decltype(chk)::value) {
             long idx = origin + (long)(off2 >> 1);
             const bool ok = live && idx >= 0 && idx < npix;
             idx = ok ? idx : 0;
             uint32_t g;
-            if constexpr (PACK) g = *reinterpret_cast<const uint16_t *>(gplane + idx * 2);
-            else g = *reinterpret_cast<const uint32_t *>(gplane + idx * 4);
+            if constexpr (PACK) {
+                const uint32_t y = (uint32_t)idx / (uint32_t)W, x = (uint32_t)idx - y * (uint32_t)W;
+                g = *reinterpret_cast<const uint16_t *>(gplane + gradp_quad_word((int)y, (int)(x >> 2), W4) * 2 + (x & 3u) * 2u);
+            } else {
+                g = *reinterpret_cast<const uint32_t *>(gplane + idx * 4);
+            }
             return ok ? g : 0u;
         } else {
-            uint32_t g;
-            if constexpr (PACK) g = *reinterpret_cast<const uint16_t *>(gwin + off2);
-            else g = *reinterpret_cast<const uint32_t *>(gwin + (off2 << 1));
+            static_assert(!PACK || decltype(chk)::value, "the internal plane has no unchecked pixel sweep");
+            const uint32_t g = *reinterpret_cast<const uint32_t *>(gwin + (off2 << 1));
             return live ? g : 0u;
         }
     };
@@ -218,9 +224,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
             add((ovsel & 0x400u) | (rl | (9u << 9)), v);
         }
     };
-    // part B entries are one dword: window row | quad of the row << 7 | 4 x c1 << 12
-    const uint32_t rowbytes = (uint32_t)W * 2u;
-    auto b_offset = [&](uint32_t e) { return (e & 0x7fu) * rowbytes + ((e >> 4) & 0xf8u); };
+    // part B entries are one dword: group of four plane rows | (quad of the row * 4 + row in the
+    // group) << 5 | 4 x c1 << 12; a group of rows is W * 8 bytes, a quad's four rows 32 bytes
+    const uint32_t groupbytes = (uint32_t)W * 8u;
+    auto b_offset = [&](uint32_t e) { return (e & 0x1fu) * groupbytes + ((e >> 2) & 0x3f8u); };
     auto b_pixels = [&](uint32_t e, uint2 q) {
         const std::false_type one;
         quad_pixel(one, q.x & 0xffffu, e >> 12, 0u);
@@ -290,17 +297,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     };
 
     // the window is rows py-35..py+35 at columns px-35..px+35 of a linearly addressed plane
-    const bool inside = origin >= 0 && origin + 70L * W + 70 < npix;
-    if (PACK && inside && origin + 70L * W + 76 <= npix) {
-        const int phase = (px - 35) & 3;             // = origin & 3 because W % 4 == 0
-        const char *gq = gplane + (origin - phase) * 2;
-        const char *tq = reinterpret_cast<const char *>(qtab) + (size_t)phase * ((size_t)qa * 8u + (size_t)qb * 4u);
-        if constexpr (NA + NB > 0) quad_static(gq, tq);
-        else quad_loops(gq, tq);
-    } else if (inside) {
-        sweep(std::false_type{});
+    if constexpr (PACK) {
+        // quad sweep: the 19 aligned quads per row that cover the window must lie in their rows
+        const int x0 = px - 35, y0 = py - 35;
+        const int xph = x0 & 3, yph = y0 & 3;        // one table per alignment of the window in the plane
+        if (x0 - xph >= 0 && x0 - xph + 76 <= W && y0 >= 0 && py + 35 < H) {
+            const char *gq = gplane + gradp_quad_word(y0 - yph, (x0 - xph) >> 2, W4) * 2;
+            const char *tq = reinterpret_cast<const char *>(qtab) + (size_t)(yph * 4 + xph) * ((size_t)qa * 8u + (size_t)qb * 4u);
+            if constexpr (NA + NB > 0) quad_static(gq, tq);
+            else quad_loops(gq, tq);
+        } else {
+            sweep(std::true_type{});
+        }
     } else {
-        sweep(std::true_type{});
+        const bool inside = origin >= 0 && origin + 70L * W + 70 < npix;
+        if (inside) sweep(std::false_type{});
+        else sweep(std::true_type{});
     }
     __syncthreads();
 

@@ -25,7 +25,7 @@
 //   candmask[y][seg]  u64, bit = pre-cull candidate (raster order; every word of the strip written)
 //   keyplane[y][x]    u32, written ONLY at candidates: (E_q15 << 8) | |D2|
 //   list[]            the candidates as (y << 16 | x), appended per strip (order irrelevant)
-//   gradp[y][x]       u16 gradp_pack(code, mag)                (internal, 2 B/pixel)
+//   gradp             u16 gradp_pack(code, mag), rows interleaved by four (gradp_quad_word; internal, 2 B/pixel)
 //   gradfull[y][x]    Grad_t {ang, mag}                        (optional, sift_detect API)
 // and it zeroes survmask / rowcount, which k_cull fills with atomics.
 #pragma once
@@ -65,6 +65,15 @@ __device__ __forceinline__ void grad_code(int gx, int gy, int &ang, int &mag)
     const uint32_t sy = (uint32_t)gy >> 31;
     const int a = (int)((sy << 2) + ((uint32_t)xm & 2u) + 1u + t);
     ang = p ? a : 0;
+}
+
+// Layout of the internal gradient plane: four image rows are interleaved quad by quad, so the
+// 4-pixel quad g of rows 4k .. 4k+3 is one 32-byte piece and a descriptor window touches a third
+// fewer cache lines than in a row-major plane (describe_kernel.h).  Offsets in 16-bit words.
+__host__ __device__ __forceinline__ size_t gradp_frame_words(int W, int H) { return (size_t)((H + 3) & ~3) * (size_t)W; }
+__device__ __forceinline__ size_t gradp_quad_word(int y, int g, int W4)
+{
+    return ((size_t)(y >> 2) * (size_t)W4 + (size_t)g) * 16u + (size_t)(y & 3) * 4u;
 }
 
 // gradp_pack(grad_code(gx, gy)) in one go: with a - 1 = 4 sy + 2 x + t (see grad_code) the word is
@@ -226,6 +235,7 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
     push(masked(Q, cmask), masked(Qh, hmask), 1);
     load_row(ys + 1, Qn, Qhn);
 
+    uint2 gb0 = make_uint2(0u, 0u), gb1 = gb0, gb2 = gb0;   // gradient words of rows 4k .. 4k+2 until row 4k+3 is done
     uint32_t qcount = 0;                              // wave-uniform
     const int th1 = max(contrastTh, 1);               // |D2| >= contrastTh (:194) and |D2| != 0 (:684) in one test
     // one image row; A, B, C = slots of rows y-1, y, y+1 (C is overwritten with row y+1)
@@ -309,7 +319,24 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
             uint2 o;
             o.x = gp[0] | (gp[1] << 16);
             o.y = gp[2] | (gp[3] << 16);
-            *reinterpret_cast<uint2 *>(gradp + fpix + (size_t)y * W + (size_t)g * 4) = o;
+            // the four rows of a group are 32 neighbouring bytes per quad: they are kept until the
+            // group is complete and leave as one piece (a strip that starts or ends inside a group
+            // stores its rows one by one); y, ys and ye are wave-uniform
+            uint16_t *const gq = gradp + gradp_frame_words(W, H) * (size_t)frame;
+            const int yr = y & 3;
+            if (yr == 3 && y - 3 >= ys) {
+                uint4 *dst = reinterpret_cast<uint4 *>(gq + gradp_quad_word(y - 3, g, W4));
+                dst[0] = make_uint4(gb0.x, gb0.y, gb1.x, gb1.y);
+                dst[1] = make_uint4(gb2.x, gb2.y, o.x, o.y);
+            } else if (y - yr < ys || (y | 3) >= ye) {
+                *reinterpret_cast<uint2 *>(gq + gradp_quad_word(y, g, W4)) = o;
+            } else if (yr == 0) {
+                gb0 = o;
+            } else if (yr == 1) {
+                gb1 = o;
+            } else {
+                gb2 = o;
+            }
         }
     };
     {

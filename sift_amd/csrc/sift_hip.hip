@@ -96,10 +96,13 @@ WindowTable build_window_table(int W)
     return t;
 }
 
-// Quad table of the describe kernel's fast path (describe_kernel.h): for each alignment
-// phase, the aligned 4-pixel quads of the 71-row window that hold a union pixel; quads with a
+// Quad table of the describe kernel's fast path (describe_kernel.h): for each alignment of the
+// window in the plane (variant = (row of the window's first row in its group of four) * 4 + column
+// phase), the aligned 4-pixel quads of the 71-row window that hold a union pixel; quads with a
 // two-circle pixel first (part A: qa entries after padding, 8 bytes each), then the rest (part B:
-// qb entries, 4 bytes each: window row | quad of the row << 7 | 4 x circle id << 12).
+// qb entries, 4 bytes each: group of rows | (quad * 4 + row in the group) << 5 | 4 x circle id << 12).
+// Both parts are ordered by address in the row-interleaved plane (detect_kernel.h), so consecutive
+// lanes read consecutive 8-byte pieces.
 struct QuadTable { std::vector<uint32_t> words; int qa = 0, qb = 0, kmax = 0; };
 QuadTable build_quad_table(int W)
 {
@@ -112,14 +115,15 @@ QuadTable build_quad_table(int W)
                 int y = SIFT_YSTART[n] + i, x = SIFT_XSTART[n] + j;
                 if (c1[y][x] == 10) c1[y][x] = n; else c2[y][x] = n;
             }
-    struct Quad { int y, q, a[4], b[4]; };
-    std::vector<Quad> A[4], B[4];
+    struct Quad { int y, q, a[4], b[4]; };          // y = window row + row phase: row from the base group's first row
+    std::vector<Quad> A[16], B[16];
     size_t na = 0, nb = 0;
-    for (int ph = 0; ph < 4; ph++) {
+    for (int v = 0; v < 16; v++) {
+        const int ph = v & 3, yph = v >> 2;
         for (int y = 0; y < 71; y++)
             for (int q = 0; q < 19; q++) {
                 Quad e;
-                e.y = y; e.q = q;
+                e.y = y + yph; e.q = q;
                 bool any = false, two = false;
                 for (int p = 0; p < 4; p++) {
                     const int x = q * 4 + p - ph;                  // window column of this pixel
@@ -128,17 +132,22 @@ QuadTable build_quad_table(int W)
                     any |= e.a[p] != 10;
                     two |= e.b[p] != 10;
                 }
-                if (two) A[ph].push_back(e);
-                else if (any) B[ph].push_back(e);
+                if (two) A[v].push_back(e);
+                else if (any) B[v].push_back(e);
             }
-        na = std::max(na, A[ph].size());
-        nb = std::max(nb, B[ph].size());
+        na = std::max(na, A[v].size());
+        nb = std::max(nb, B[v].size());
     }
+    // bytes from the base: (group of rows) * W * 8 + quad * 32 + (row in the group) * 8
+    auto low = [](const Quad &e) { return (e.q * 4 + (e.y & 3)) * 8; };
+    auto before = [&](const Quad &l, const Quad &r) { return (l.y >> 2) != (r.y >> 2) ? (l.y >> 2) < (r.y >> 2) : low(l) < low(r); };
     QuadTable t;
     t.qa = (int)((na + 63) / 64 * 64);
     t.qb = (int)((nb + 63) / 64 * 64);
     const Quad nop = {0, 0, {10, 10, 10, 10}, {10, 10, 10, 10}};   // offset 0, every pixel -> spare rows
-    for (int ph = 0; ph < 4; ph++) {
+    for (int ph = 0; ph < 16; ph++) {
+        std::sort(A[ph].begin(), A[ph].end(), before);
+        std::sort(B[ph].begin(), B[ph].end(), before);
         A[ph].resize((size_t)t.qa, nop);
         B[ph].resize((size_t)t.qb, nop);
         // pixels per (LDS column, circle | overlap) of this phase; entry i falls to column i % 32
@@ -146,7 +155,7 @@ QuadTable build_quad_table(int W)
         memset(k, 0, sizeof k);
         for (size_t i = 0; i < A[ph].size(); i++) {
             const Quad &e = A[ph][i];
-            uint32_t lo = (uint32_t)(e.y * W * 2 + e.q * 8), hi = 0;
+            uint32_t lo = (uint32_t)((e.y >> 2) * W * 8 + low(e)), hi = 0;
             for (int p = 0; p < 4; p++) {
                 if (e.a[p] < 9) k[i % 32][e.a[p]]++;
                 if (e.b[p] < 9) { k[i % 32][e.b[p]]++; k[i % 32][9]++; }
@@ -158,7 +167,7 @@ QuadTable build_quad_table(int W)
         }
         for (size_t i = 0; i < B[ph].size(); i++) {
             const Quad &e = B[ph][i];
-            uint32_t w = (uint32_t)e.y | (uint32_t)e.q << 7;
+            uint32_t w = (uint32_t)(e.y >> 2) | (uint32_t)(e.q * 4 + (e.y & 3)) << 5;
             for (int p = 0; p < 4; p++) {
                 if (e.a[p] < 9) k[i % 32][e.a[p]]++;
                 w |= (uint32_t)e.a[p] << (12 + 4 * p);
@@ -455,7 +464,7 @@ int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int m
     A((void **)&c->d_surv, B * HS * 8);
     A((void **)&c->d_key, B * np * 4);
     A((void **)&c->d_rowcount, B * (size_t)height * 4);
-    A((void **)&c->d_gradp, B * np * 2);
+    A((void **)&c->d_gradp, B * sift::gradp_frame_words(width, height) * 2);
     A((void **)&c->d_kps, B * (size_t)max_keypoints * 8);
     A((void **)&c->d_desc, B * (size_t)max_keypoints * 72 * 4);
     A((void **)&c->d_total, B * 4);

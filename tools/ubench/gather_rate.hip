@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdint.h>
 #include <vector>
+#include <algorithm>
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 // NEAR > 0: the waves of a block read windows within NEAR pixels of the block's origin (spatial neighbours)
@@ -134,6 +135,18 @@ int main()
         CHECK(hipMemcpy(orig, o.data(), o.size() * 4, hipMemcpyHostToDevice));
         if (al == 0) {
             if (shape_case<71, 19, 1>(plane, orig, out, W, blocks, iters)) return 1;
+            {   // windows in raster order per frame (2048 per frame), as k_describe's slots are
+                std::vector<uint32_t> so(o);
+                std::sort(so.begin(), so.end());
+                uint32_t *sorig; CHECK(hipMalloc(&sorig, so.size() * 4));
+                CHECK(hipMemcpy(sorig, so.data(), so.size() * 4, hipMemcpyHostToDevice));
+                printf("raster-ordered windows (the 'random' column; 'neighbouring' as before):\n");
+                if (shape_case<71, 19, 1>(plane, sorig, out, W, blocks, iters)) return 1;
+                if (shape_case<36, 38, 2>(plane, sorig, out, W, blocks, iters)) return 1;
+                if (shape_case<18, 76, 4>(plane, sorig, out, W, blocks, iters)) return 1;
+                if (shape_case<9, 152, 8>(plane, sorig, out, W, blocks, iters)) return 1;
+                printf("random windows again:\n");
+            }
             {
                 hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
                 float m1 = 0, m8 = 0;
