@@ -38,8 +38,12 @@
 // pixels keeps the texture addresser busy for the whole kernel (measured:
 // TA_BUSY = 100 %, ~30 cache accesses per gather).  Keypoints whose window lies
 // inside the plane therefore read the window as aligned 8-byte quads (4 pixels
-// per lane, consecutive lanes = consecutive quads of a window row), from a
-// second table with one variant per alignment phase (px-35) & 3:
+// per lane).  The internal plane interleaves four image rows quad by quad
+// (detect_kernel.h: gradp_quad_word), so the window's quads of four rows lie in
+// one run of 19 x 32 bytes and a window touches 139 instead of 228 cache lines.
+// A second table has one variant per alignment of the window in that plane
+// ((py-35) & 3 rows into a group, (px-35) & 3 columns into a quad); its entries
+// are ordered by address, consecutive lanes = consecutive 8-byte pieces:
 //   lo = byte offset of the quad from the aligned window base | notov bits << 24
 //   hi = 4 x (c1 | c2 << 4), one byte per pixel of the quad
 // with circle id 9 = the overlap bins and 10, 11 = "not in the union" / "not an
@@ -224,16 +228,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
             add((ovsel & 0x400u) | (rl | (9u << 9)), v);
         }
     };
-    // part B entries are one dword: group of four plane rows | (quad of the row * 4 + row in the
-    // group) << 5 | 4 x c1 << 12; a group of rows is W * 8 bytes, a quad's four rows 32 bytes
+    // part B entries are one dword: group of four plane rows | 4 x c1 << 9 | (quad of the row * 4 +
+    // row in the group) << 25; a group of rows is W * 8 bytes, a quad's four rows 32 bytes.  The
+    // first pixel's circle id stands where the LDS row offset needs it (one v_and_or).
     const uint32_t groupbytes = (uint32_t)W * 8u;
-    auto b_offset = [&](uint32_t e) { return (e & 0x1fu) * groupbytes + ((e >> 2) & 0x3f8u); };
+    auto b_offset = [&](uint32_t e) { return (e & 0x1fu) * groupbytes + ((e >> 22) & 0x3f8u); };
     auto b_pixels = [&](uint32_t e, uint2 q) {
         const std::false_type one;
-        quad_pixel(one, q.x & 0xffffu, e >> 12, 0u);
-        quad_pixel(one, q.x >> 16, e >> 16, 0u);
-        quad_pixel(one, q.y & 0xffffu, e >> 20, 0u);
-        quad_pixel(one, q.y >> 16, e >> 24, 0u);
+        {
+            const uint32_t g = q.x & 0xffffu;
+            add((e & 0x1e00u) | ((((g >> 9) & 3u) << 7) | col4), (g & 0x1ffu) << (g >> 11));
+        }
+        quad_pixel(one, q.x >> 16, e >> 13, 0u);
+        quad_pixel(one, q.y & 0xffffu, e >> 17, 0u);
+        quad_pixel(one, q.y >> 16, e >> 21, 0u);
     };
     auto a_pixels = [&](uint2 e, uint2 q) {
         const std::true_type two;

@@ -100,7 +100,7 @@ WindowTable build_window_table(int W)
 // window in the plane (variant = (row of the window's first row in its group of four) * 4 + column
 // phase), the aligned 4-pixel quads of the 71-row window that hold a union pixel; quads with a
 // two-circle pixel first (part A: qa entries after padding, 8 bytes each), then the rest (part B:
-// qb entries, 4 bytes each: group of rows | (quad * 4 + row in the group) << 5 | 4 x circle id << 12).
+// qb entries, 4 bytes each: group of rows | 4 x circle id << 9 | (quad * 4 + row in the group) << 25).
 // Both parts are ordered by address in the row-interleaved plane (detect_kernel.h), so consecutive
 // lanes read consecutive 8-byte pieces.
 struct QuadTable { std::vector<uint32_t> words; int qa = 0, qb = 0, kmax = 0; };
@@ -167,10 +167,10 @@ QuadTable build_quad_table(int W)
         }
         for (size_t i = 0; i < B[ph].size(); i++) {
             const Quad &e = B[ph][i];
-            uint32_t w = (uint32_t)(e.y >> 2) | (uint32_t)(e.q * 4 + (e.y & 3)) << 5;
+            uint32_t w = (uint32_t)(e.y >> 2) | (uint32_t)(e.q * 4 + (e.y & 3)) << 25;
             for (int p = 0; p < 4; p++) {
                 if (e.a[p] < 9) k[i % 32][e.a[p]]++;
-                w |= (uint32_t)e.a[p] << (12 + 4 * p);
+                w |= (uint32_t)e.a[p] << (9 + 4 * p);
             }
             t.words.push_back(w);
         }
