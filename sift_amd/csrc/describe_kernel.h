@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     // row in the group) << 25; a group of rows is W * 8 bytes, a quad's four rows 32 bytes.  The
     // first pixel's circle id stands where the LDS row offset needs it (one v_and_or).
     const uint32_t groupbytes = (uint32_t)W * 8u;
-    auto b_offset = [&](uint32_t e) { return (e & 0x1fu) * groupbytes + ((e >> 22) & 0x3f8u); };
+    auto b_offset = [&](uint32_t e) { return __umul24(e & 0x1fu, groupbytes) + ((e >> 22) & 0x3f8u); };   // W * 8 < 2^24
     auto b_pixels = [&](uint32_t e, uint2 q) {
         const std::false_type one;
         {
@@ -363,9 +363,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
         for (int n = 0; n < 9; n++) v += fin[n * 8 + a];
         // (int)v > 0 is the reference's test; the key orders by value, then by smaller a
         uint32_t key = ((int)v > 0) ? ((v << 3) | (uint32_t)(7 - a)) : 0u;
-        key = max(key, (uint32_t)__shfl_xor((int)key, 1));
-        key = max(key, (uint32_t)__shfl_xor((int)key, 2));
-        key = max(key, (uint32_t)__shfl_xor((int)key, 4));
+        // max over the 8 lanes of a group: lanes ^1 and ^2 by quad permutes; after those the two
+        // quads of a group are uniform, so the mirror of the 8 lanes supplies the other quad
+        key = max(key, dpp_mov<0xB1>(key));              // quad_perm:[1,0,3,2]
+        key = max(key, dpp_mov<0x4E>(key));              // quad_perm:[2,3,0,1]
+        key = max(key, dpp_mov<0x141>(key));             // row_half_mirror
         m = key ? 8u - (key & 7u) : 0u;
         if (ori_out && lane == 0) ori_out[slot] = (uint8_t)m;
     }
