@@ -154,7 +154,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
             uint32_t g;
             if constexpr (PACK) {
                 const uint32_t y = (uint32_t)idx / (uint32_t)W, x = (uint32_t)idx - y * (uint32_t)W;
-                g = *reinterpret_cast<const uint16_t *>(gplane + gradp_quad_word((int)y, (int)(x >> 2), W4) * 2 + (x & 3u) * 2u);
+                const uint32_t pair = *reinterpret_cast<const uint32_t *>(gplane + gradp_quad_word((int)y, (int)(x >> 2), W4) * 2 + (x & 2u) * 2u);
+                g = gradp_unpack(pair, x & 1u);
             } else {
                 g = *reinterpret_cast<const uint32_t *>(gplane + idx * 4);
             }
@@ -217,11 +218,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
         part(chk, std::false_type{}, n2pad, ntab);
     };
     // quad sweep (internal format, window inside the plane)
-    auto quad_pixel = [&](auto two, uint32_t g, uint32_t cc, uint32_t ovsel) {
-        // g = gradp word; cc = c1 | c2 << 4 in its low byte; ovsel bit 10 set = not an overlap
+    // value (magnitude in its half of the bin pair) and LDS row offset of the even / odd pixel of a
+    // pair dword (detect_kernel.h: gradp_pack); the shift counts rely on five-bit shifts
+    auto pair_v = [](auto odd, uint32_t d) {
+        if constexpr (decltype(odd)::value) return ((d >> 9) & 0x1ffu) << ((d >> 18) & 31u);
+        else return (d >> 23) << (d & 31u);
+    };
+    auto pair_rl = [&](auto odd, uint32_t d) {
+        if constexpr (decltype(odd)::value) return (d & 0x180u) | col4;
+        else return ((d << 2) & 0x180u) | col4;
+    };
+    auto quad_pixel = [&](auto two, auto odd, uint32_t d, uint32_t cc, uint32_t ovsel) {
+        // d = pair dword; cc = c1 | c2 << 4 in its low byte; ovsel bit 10 set = not an overlap
         // pixel: circle id 9 | 2 = 11, a spare row like id 10
-        const uint32_t v = (g & 0x1ffu) << (g >> 11);
-        const uint32_t rl = (((g >> 9) & 3u) << 7) | col4;
+        const uint32_t v = pair_v(odd, d);
+        const uint32_t rl = pair_rl(odd, d);
         add(((cc & 15u) << 9) | rl, v);
         if constexpr (decltype(two)::value) {
             add((((cc >> 4) & 15u) << 9) | rl, v);
@@ -235,20 +246,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     auto b_offset = [&](uint32_t e) { return __umul24(e & 0x1fu, groupbytes) + ((e >> 22) & 0x3f8u); };   // W * 8 < 2^24
     auto b_pixels = [&](uint32_t e, uint2 q) {
         const std::false_type one;
-        {
-            const uint32_t g = q.x & 0xffffu;
-            add((e & 0x1e00u) | ((((g >> 9) & 3u) << 7) | col4), (g & 0x1ffu) << (g >> 11));
-        }
-        quad_pixel(one, q.x >> 16, e >> 13, 0u);
-        quad_pixel(one, q.y & 0xffffu, e >> 17, 0u);
-        quad_pixel(one, q.y >> 16, e >> 21, 0u);
+        const std::false_type even;
+        const std::true_type odd;
+        add((e & 0x1e00u) | pair_rl(even, q.x), pair_v(even, q.x));
+        quad_pixel(one, odd, q.x, e >> 13, 0u);
+        quad_pixel(one, even, q.y, e >> 17, 0u);
+        quad_pixel(one, odd, q.y, e >> 21, 0u);
     };
     auto a_pixels = [&](uint2 e, uint2 q) {
         const std::true_type two;
-        quad_pixel(two, q.x & 0xffffu, e.y, e.x >> 14);
-        quad_pixel(two, q.x >> 16, e.y >> 8, e.x >> 15);
-        quad_pixel(two, q.y & 0xffffu, e.y >> 16, e.x >> 16);
-        quad_pixel(two, q.y >> 16, e.y >> 24, e.x >> 17);
+        const std::false_type even;
+        const std::true_type odd;
+        quad_pixel(two, even, q.x, e.y, e.x >> 14);
+        quad_pixel(two, odd, q.x, e.y >> 8, e.x >> 15);
+        quad_pixel(two, even, q.y, e.y >> 16, e.x >> 16);
+        quad_pixel(two, odd, q.y, e.y >> 24, e.x >> 17);
     };
     // tq: this phase's table, qa 8-byte entries (part A) followed by qb 4-byte entries (part B)
     auto chunk_a = [&](auto nu, const char *gq, const char *tq, int t0) {

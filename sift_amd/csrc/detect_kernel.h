@@ -25,7 +25,7 @@
 //   candmask[y][seg]  u64, bit = pre-cull candidate (raster order; every word of the strip written)
 //   keyplane[y][x]    u32, written ONLY at candidates: (E_q15 << 8) | |D2|
 //   list[]            the candidates as (y << 16 | x), appended per strip (order irrelevant)
-//   gradp             u16 gradp_pack(code, mag), rows interleaved by four (gradp_quad_word; internal, 2 B/pixel)
+//   gradp             gradp_pack(code, mag) per pair of pixels, rows interleaved by four (gradp_quad_word; internal, 2 B/pixel)
 //   gradfull[y][x]    Grad_t {ang, mag}                        (optional, sift_detect API)
 // and it zeroes survmask / rowcount, which k_cull fills with atomics.
 #pragma once
@@ -37,14 +37,24 @@ namespace sift {
 
 typedef unsigned long long u64;
 
-// internal 2-byte gradient word (written by k_detect, read by k_describe), a = code - 1:
-//   bits 0-8 mag, bits 9-10 a >> 1, bits 11-14 zero, bit 15 a & 1     (0 for code 0, whose
-// magnitude never reaches a descriptor bin).  word >> 11 is then the shift (0 or 16) that puts
-// the magnitude into the 16-bit half of its LDS bin pair.
-__device__ __forceinline__ uint32_t gradp_pack(int ang, int mag)
+// Internal gradient plane (written by k_detect, read by k_describe): 2 bytes per pixel, one dword
+// per pair of pixels (E = even column, O = odd column), a = code - 1, dir = a >> 1, b = a & 1:
+//   bits 0-3 zero | 4 b_E | 5-6 dir_E | 7-8 dir_O | 9-17 mag_O | 18-21 zero | 22 b_O | 23-31 mag_E
+// and all fields of a pixel 0 for code 0, whose magnitude never reaches a descriptor bin.  The
+// fields stand where k_describe needs them: the dword itself (E) or dword >> 18 (O) is the shift
+// count 16 b (v_lshlrev looks at five bits) that puts the magnitude into its half of the LDS bin
+// pair, dword & 0x180 is O's LDS row offset, dword >> 23 is E's magnitude.
+__device__ __forceinline__ uint32_t gradp_pack(int ang, int mag, bool odd)
 {
-    const uint32_t a = (uint32_t)(ang - 1);
-    return ang ? ((uint32_t)mag | ((a >> 1) << 9) | ((a & 1u) << 15)) : 0u;
+    const uint32_t a = (uint32_t)(ang - 1), dir = a >> 1, b = a & 1u;
+    const uint32_t w = odd ? ((uint32_t)mag << 9 | dir << 7 | b << 22) : ((uint32_t)mag << 23 | dir << 5 | b << 4);
+    return ang ? w : 0u;
+}
+// the pixel's fields in the order mag | dir << 9 | b << 15 (the pixel sweep of k_describe)
+__device__ __forceinline__ uint32_t gradp_unpack(uint32_t pair, bool odd)
+{
+    return odd ? (((pair >> 9) & 0x1ffu) | ((pair >> 7) & 3u) << 9 | ((pair >> 22) & 1u) << 15)
+               : ((pair >> 23) | ((pair >> 5) & 3u) << 9 | ((pair >> 4) & 1u) << 15);
 }
 
 // ComputeGradientKernel (:1186-1225), branch-free.
@@ -76,9 +86,9 @@ __device__ __forceinline__ size_t gradp_quad_word(int y, int g, int W4)
     return ((size_t)(y >> 2) * (size_t)W4 + (size_t)g) * 16u + (size_t)(y & 3) * 4u;
 }
 
-// gradp_pack(grad_code(gx, gy)) in one go: with a - 1 = 4 sy + 2 x + t (see grad_code) the word is
-// mag | (2 sy + x) << 9 | t << 15, and 0 where gx * gy == 0
-__device__ __forceinline__ uint32_t grad_word(int gx, int gy)
+// gradp_pack(grad_code(gx, gy)) in one go: with a - 1 = 4 sy + 2 x + t (see grad_code), dir is
+// 2 sy + x and b is t; 0 where gx * gy == 0
+__device__ __forceinline__ uint32_t grad_word(int gx, int gy, bool odd)
 {
     const int gx2 = gx * gx, gy2 = gy * gy;
     const uint32_t mag = (uint32_t)(int)__builtin_amdgcn_sqrtf((float)(gx2 + gy2) + 0.5f);
@@ -87,7 +97,8 @@ __device__ __forceinline__ uint32_t grad_word(int gx, int gy)
     const int dd = ((gx2 - gy2) ^ xm) - xm;
     const uint32_t t = (uint32_t)(dd - 1) >> 31;
     const uint32_t sy = (uint32_t)gy >> 31;
-    const uint32_t w = mag | (((sy << 1) | ((uint32_t)xm & 1u)) << 9) | (t << 15);
+    const uint32_t w = odd ? (mag << 9 | (sy << 8 | ((uint32_t)xm & 0x80u)) | t << 22)
+                           : (mag << 23 | (sy << 6 | ((uint32_t)xm & 0x20u)) | t << 4);
     return p ? w : 0u;
 }
 
@@ -307,18 +318,18 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
                 if constexpr (FULLGRAD) {
                     int ang, mag;
                     grad_code(gx, gy, ang, mag);
-                    gp[p] = gradp_pack(ang, mag);
+                    gp[p] = gradp_pack(ang, mag, p & 1);
                     gf[p] = (uint32_t)ang | ((uint32_t)mag << 16);        // Grad_t {angGrad, magGrad}
                 } else {
-                    gp[p] = grad_word(gx, gy);
+                    gp[p] = grad_word(gx, gy, p & 1);
                     gf[p] = 0;
                 }
             }
             if constexpr (FULLGRAD)
                 *reinterpret_cast<uint4 *>(gradfull + fpix + (size_t)y * W + (size_t)g * 4) = make_uint4(gf[0], gf[1], gf[2], gf[3]);
             uint2 o;
-            o.x = gp[0] | (gp[1] << 16);
-            o.y = gp[2] | (gp[3] << 16);
+            o.x = gp[0] | gp[1];
+            o.y = gp[2] | gp[3];
             // the four rows of a group are 32 neighbouring bytes per quad: they are kept until the
             // group is complete and leave as one piece (a strip that starts or ends inside a group
             // stores its rows one by one); y, ys and ye are wave-uniform
