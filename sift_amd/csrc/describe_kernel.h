@@ -85,14 +85,14 @@ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)   // v_pk_add
 }
 
 // grid: x = max_kp keypoints, y = frames; block = 64 (one wave)
-// NA, NB > 0: the quad table has exactly NA and NB steps of 64 quads (the reference's masks: 5 and
-// 11) and the sweep is straight-line code with every load of the window in flight at once
-template <int GFMT, int MODE, bool LOOP = false, int NA = 0, int NB = 0>
+// NA, NU, NB > 0: the quad table has exactly NA, NU and NB steps of 64 quads (the reference's masks:
+// 5, 9 and 2) and the sweep is straight-line code with every load of the window in flight at once
+template <int GFMT, int MODE, bool LOOP = false, int NA = 0, int NU = 0, int NB = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_describe(const void *__restrict__ gradv, const kp_t *__restrict__ kps,
                                                  const uint8_t *__restrict__ ori_in, uint8_t *__restrict__ ori_out,
                                                  uint32_t *__restrict__ desc, const uint2 *__restrict__ tab,
                                                  int n2, int n2pad, int ntab, const void *__restrict__ qtab,
-                                                 int qa, int qb, const uint32_t *__restrict__ total, int W, int H,
+                                                 int qa, int qu, int qb, const uint32_t *__restrict__ total, int W, int H,
                                                  int max_kp)
 {
     constexpr bool PACK = GFMT == GRAD_PACKED16;
@@ -224,10 +224,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
         if constexpr (decltype(odd)::value) return ((d >> 9) & 0x1ffu) << ((d >> 18) & 31u);
         else return (d >> 23) << (d & 31u);
     };
-    auto pair_rl = [&](auto odd, uint32_t d) {
-        if constexpr (decltype(odd)::value) return (d & 0x180u) | col4;
-        else return ((d << 2) & 0x180u) | col4;
+    auto pair_rl_at = [](auto odd, uint32_t d, uint32_t base) {
+        if constexpr (decltype(odd)::value) return (d & 0x180u) | base;
+        else return ((d << 2) & 0x180u) | base;
     };
+    auto pair_rl = [&](auto odd, uint32_t d) { return pair_rl_at(odd, d, col4); };
     auto quad_pixel = [&](auto two, auto odd, uint32_t d, uint32_t cc, uint32_t ovsel) {
         // d = pair dword; cc = c1 | c2 << 4 in its low byte; ovsel bit 10 set = not an overlap
         // pixel: circle id 9 | 2 = 11, a spare row like id 10
@@ -253,6 +254,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
         quad_pixel(one, even, q.y, e >> 17, 0u);
         quad_pixel(one, odd, q.y, e >> 21, 0u);
     };
+    // part U entries are 16 bits, for quads whose four pixels lie in one circle and in no other (most
+    // of the window): (quad * 4 + row in the group) | group << 7 | circle id << 12.  The circle's LDS
+    // offset is formed once per quad; an odd pixel's address is then one v_and_or.
+    auto u_offset = [&](uint32_t e) { return __umul24((e >> 7) & 0x1fu, groupbytes) + ((e << 3) & 0x3f8u); };
+    auto u_pixels = [&](uint32_t e, uint2 q) {
+        const std::false_type even;
+        const std::true_type odd;
+        const uint32_t cbase = ((e >> 3) & 0x1e00u) | col4;
+        add(pair_rl_at(even, q.x, cbase), pair_v(even, q.x));
+        add(pair_rl_at(odd, q.x, cbase), pair_v(odd, q.x));
+        add(pair_rl_at(even, q.y, cbase), pair_v(even, q.y));
+        add(pair_rl_at(odd, q.y, cbase), pair_v(odd, q.y));
+    };
     auto a_pixels = [&](uint2 e, uint2 q) {
         const std::true_type two;
         const std::false_type even;
@@ -262,7 +276,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
         quad_pixel(two, even, q.y, e.y >> 16, e.x >> 16);
         quad_pixel(two, odd, q.y, e.y >> 24, e.x >> 17);
     };
-    // tq: this phase's table, qa 8-byte entries (part A) followed by qb 4-byte entries (part B)
+    // tq: this phase's table, qa 8-byte entries (part A), qu 2-byte entries (part U), qb 4-byte entries (part B)
     auto chunk_a = [&](auto nu, const char *gq, const char *tq, int t0) {
         constexpr int N = decltype(nu)::value;
         uint2 e[N], q[N];
@@ -286,23 +300,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
 #pragma unroll
         for (int u = 0; u < N; u++) b_pixels(e[u], q[u]);
     };
+    auto chunk_u = [&](auto nu, const char *gq, const char *tu0, int t0) {
+        constexpr int N = decltype(nu)::value;
+        uint32_t e[N];
+        uint2 q[N];
+        const uint32_t tb = (uint32_t)(t0 + lane) * 2u;
+#pragma unroll
+        for (int u = 0; u < N; u++) e[u] = *reinterpret_cast<const uint16_t *>(tu0 + tb + (uint32_t)u * 128u);
+#pragma unroll
+        for (int u = 0; u < N; u++) q[u] = *reinterpret_cast<const uint2 *>(gq + u_offset(e[u]));
+#pragma unroll
+        for (int u = 0; u < N; u++) u_pixels(e[u], q[u]);
+    };
     // A wave's time is mostly load latency (table entry -> quad -> adds), so the static variant
-    // issues all NA + NB table loads, then all gathers, and only then starts adding.
+    // issues all NA + NU + NB table loads, then all gathers, and only then starts adding.
     auto quad_static = [&](const char *gq, const char *tq) {
-        constexpr int MA = NA > 0 ? NA : 1, MB = NB > 0 ? NB : 1;
-        uint2 ea[MA], qa_[MA], qb_[MB];
-        uint32_t eb[MB];
-        const char *tb0 = tq + (size_t)NA * 512u;
+        constexpr int MA = NA > 0 ? NA : 1, MU = NU > 0 ? NU : 1, MB = NB > 0 ? NB : 1;
+        uint2 ea[MA], qa_[MA], qu_[MU], qb_[MB];
+        uint32_t eu[MU], eb[MB];
+        const char *tu0 = tq + (size_t)NA * 512u;
+        const char *tb0 = tu0 + (size_t)NU * 128u;
 #pragma unroll
         for (int u = 0; u < NA; u++) ea[u] = *reinterpret_cast<const uint2 *>(tq + (uint32_t)lane * 8u + (uint32_t)u * 512u);
+#pragma unroll
+        for (int u = 0; u < NU; u++) eu[u] = *reinterpret_cast<const uint16_t *>(tu0 + (uint32_t)lane * 2u + (uint32_t)u * 128u);
 #pragma unroll
         for (int u = 0; u < NB; u++) eb[u] = *reinterpret_cast<const uint32_t *>(tb0 + (uint32_t)lane * 4u + (uint32_t)u * 256u);
 #pragma unroll
         for (int u = 0; u < NA; u++) qa_[u] = *reinterpret_cast<const uint2 *>(gq + (ea[u].x & 0xffffffu));
 #pragma unroll
+        for (int u = 0; u < NU; u++) qu_[u] = *reinterpret_cast<const uint2 *>(gq + u_offset(eu[u]));
+#pragma unroll
         for (int u = 0; u < NB; u++) qb_[u] = *reinterpret_cast<const uint2 *>(gq + b_offset(eb[u]));
 #pragma unroll
         for (int u = 0; u < NA; u++) a_pixels(ea[u], qa_[u]);
+#pragma unroll
+        for (int u = 0; u < NU; u++) u_pixels(eu[u], qu_[u]);
 #pragma unroll
         for (int u = 0; u < NB; u++) b_pixels(eb[u], qb_[u]);
     };
@@ -310,7 +343,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
         int t0 = 0;
         for (; t0 + 64 * U <= qa; t0 += 64 * U) chunk_a(std::integral_constant<int, U>{}, gq, tq, t0);
         for (; t0 < qa; t0 += 64) chunk_a(std::integral_constant<int, 1>{}, gq, tq, t0);
-        const char *tb0 = tq + (size_t)qa * 8u;
+        const char *tu0 = tq + (size_t)qa * 8u;
+        t0 = 0;
+        for (; t0 + 64 * U <= qu; t0 += 64 * U) chunk_u(std::integral_constant<int, U>{}, gq, tu0, t0);
+        for (; t0 < qu; t0 += 64) chunk_u(std::integral_constant<int, 1>{}, gq, tu0, t0);
+        const char *tb0 = tu0 + (size_t)qu * 2u;
         t0 = 0;
         for (; t0 + 64 * U <= qb; t0 += 64 * U) chunk_b(std::integral_constant<int, U>{}, gq, tb0, t0);
         for (; t0 < qb; t0 += 64) chunk_b(std::integral_constant<int, 1>{}, gq, tb0, t0);
@@ -323,8 +360,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
         const int xph = x0 & 3, yph = y0 & 3;        // one table per alignment of the window in the plane
         if (x0 - xph >= 0 && x0 - xph + 76 <= W && y0 >= 0 && py + 35 < H) {
             const char *gq = gplane + gradp_quad_word(y0 - yph, (x0 - xph) >> 2, W4) * 2;
-            const char *tq = reinterpret_cast<const char *>(qtab) + (size_t)(yph * 4 + xph) * ((size_t)qa * 8u + (size_t)qb * 4u);
-            if constexpr (NA + NB > 0) quad_static(gq, tq);
+            const char *tq = reinterpret_cast<const char *>(qtab) + (size_t)(yph * 4 + xph) * ((size_t)qa * 8u + (size_t)qu * 2u + (size_t)qb * 4u);
+            if constexpr (NA + NU + NB > 0) quad_static(gq, tq);
             else quad_loops(gq, tq);
         } else {
             sweep(std::true_type{});

@@ -99,11 +99,13 @@ WindowTable build_window_table(int W)
 // Quad table of the describe kernel's fast path (describe_kernel.h): for each alignment of the
 // window in the plane (variant = (row of the window's first row in its group of four) * 4 + column
 // phase), the aligned 4-pixel quads of the 71-row window that hold a union pixel; quads with a
-// two-circle pixel first (part A: qa entries after padding, 8 bytes each), then the rest (part B:
-// qb entries, 4 bytes each: group of rows | 4 x circle id << 9 | (quad * 4 + row in the group) << 25).
-// Both parts are ordered by address in the row-interleaved plane (detect_kernel.h), so consecutive
+// two-circle pixel first (part A: qa entries after padding, 8 bytes each), then quads that lie in one
+// circle with all four pixels (part U: qu entries, 2 bytes each: (quad * 4 + row in the group) |
+// group of rows << 7 | circle id << 12), then the rest (part B: qb entries, 4 bytes each: group of
+// rows | 4 x circle id << 9 | (quad * 4 + row in the group) << 25).
+// All parts are ordered by address in the row-interleaved plane (detect_kernel.h), so consecutive
 // lanes read consecutive 8-byte pieces.
-struct QuadTable { std::vector<uint32_t> words; int qa = 0, qb = 0, kmax = 0; };
+struct QuadTable { std::vector<uint8_t> bytes; int qa = 0, qu = 0, qb = 0, kmax = 0; };
 QuadTable build_quad_table(int W)
 {
     int c1[71][71], c2[71][71];
@@ -116,35 +118,47 @@ QuadTable build_quad_table(int W)
                 if (c1[y][x] == 10) c1[y][x] = n; else c2[y][x] = n;
             }
     struct Quad { int y, q, a[4], b[4]; };          // y = window row + row phase: row from the base group's first row
-    std::vector<Quad> A[16], B[16];
-    size_t na = 0, nb = 0;
+    std::vector<Quad> A[16], U[16], B[16];
+    size_t na = 0, nu = SIZE_MAX;
     for (int v = 0; v < 16; v++) {
         const int ph = v & 3, yph = v >> 2;
         for (int y = 0; y < 71; y++)
             for (int q = 0; q < 19; q++) {
                 Quad e;
                 e.y = y + yph; e.q = q;
-                bool any = false, two = false;
+                bool any = false, two = false, uniform = true;
                 for (int p = 0; p < 4; p++) {
                     const int x = q * 4 + p - ph;                  // window column of this pixel
                     e.a[p] = e.b[p] = 10;
                     if (x >= 0 && x < 71) { e.a[p] = c1[y][x]; e.b[p] = c2[y][x]; }
                     any |= e.a[p] != 10;
                     two |= e.b[p] != 10;
+                    uniform &= e.a[p] != 10 && e.a[p] == e.a[0];
                 }
                 if (two) A[v].push_back(e);
+                else if (uniform) U[v].push_back(e);
                 else if (any) B[v].push_back(e);
             }
         na = std::max(na, A[v].size());
-        nb = std::max(nb, B[v].size());
+        nu = std::min(nu, U[v].size());
     }
     // bytes from the base: (group of rows) * W * 8 + quad * 32 + (row in the group) * 8
     auto low = [](const Quad &e) { return (e.q * 4 + (e.y & 3)) * 8; };
     auto before = [&](const Quad &l, const Quad &r) { return (l.y >> 2) != (r.y >> 2) ? (l.y >> 2) < (r.y >> 2) : low(l) < low(r); };
     QuadTable t;
     t.qa = (int)((na + 63) / 64 * 64);
+    t.qu = (int)(nu / 64 * 64);                     // whole steps only: the other one-circle quads go to part B
+    size_t nb = 0;
+    for (int v = 0; v < 16; v++) {
+        std::sort(U[v].begin(), U[v].end(), before);
+        B[v].insert(B[v].end(), U[v].begin() + t.qu, U[v].end());
+        U[v].resize((size_t)t.qu);
+        nb = std::max(nb, B[v].size());
+    }
     t.qb = (int)((nb + 63) / 64 * 64);
     const Quad nop = {0, 0, {10, 10, 10, 10}, {10, 10, 10, 10}};   // offset 0, every pixel -> spare rows
+    auto put16 = [&](uint32_t w) { t.bytes.push_back((uint8_t)w); t.bytes.push_back((uint8_t)(w >> 8)); };
+    auto put32 = [&](uint32_t w) { put16(w); put16(w >> 16); };
     for (int ph = 0; ph < 16; ph++) {
         std::sort(A[ph].begin(), A[ph].end(), before);
         std::sort(B[ph].begin(), B[ph].end(), before);
@@ -162,8 +176,13 @@ QuadTable build_quad_table(int W)
                 hi |= (uint32_t)(e.a[p] | e.b[p] << 4) << (8 * p);
                 if (e.b[p] == 10) lo |= 1u << (24 + p);            // notov: the third add goes to the spare rows
             }
-            t.words.push_back(lo);
-            t.words.push_back(hi);
+            put32(lo);
+            put32(hi);
+        }
+        for (size_t i = 0; i < U[ph].size(); i++) {
+            const Quad &e = U[ph][i];
+            k[i % 32][e.a[0]] += 4;
+            put16((uint32_t)(e.q * 4 + (e.y & 3)) | (uint32_t)(e.y >> 2) << 7 | (uint32_t)e.a[0] << 12);
         }
         for (size_t i = 0; i < B[ph].size(); i++) {
             const Quad &e = B[ph][i];
@@ -172,7 +191,7 @@ QuadTable build_quad_table(int W)
                 if (e.a[p] < 9) k[i % 32][e.a[p]]++;
                 w |= (uint32_t)e.a[p] << (9 + 4 * p);
             }
-            t.words.push_back(w);
+            put32(w);
         }
         for (int c = 0; c < 32; c++)
             for (int n = 0; n < 10; n++) t.kmax = std::max(t.kmax, k[c][n]);
@@ -211,7 +230,7 @@ struct sift_hip_ctx {
     size_t bgr_cap = 0;
     uint2 *d_tab = nullptr;
     uint32_t *d_qtab = nullptr;           // quad table (build_quad_table)
-    int ntab = 0, n2 = 0, n2pad = 0, qa = 0, qb = 0;
+    int ntab = 0, n2 = 0, n2pad = 0, qa = 0, qu = 0, qb = 0;
     int blur_rows = 0;
     // graph of the last fused call (small batches: launch gaps are a third of a single frame's time)
     struct GraphKey { const void *imgs = nullptr, *kps = nullptr, *desc = nullptr, *total = nullptr; int nframes = 0, th = 0, brows = 0, drows = 0; } gkey;
@@ -351,18 +370,18 @@ int run_describe(sift_hip_ctx *c, const void *d_grad, int nframes, const sift::k
     dim3 grid(std::min(gx, c->max_kp), nframes);
     const uint32_t *tot = fused ? (const uint32_t *)c->d_total_ctx : (const uint32_t *)nullptr;
     // the reference's masks give 5 + 11 steps of 64 quads: straight-line variant
-    if (GFMT == sift::GRAD_PACKED16 && (int)grid.x == c->max_kp && c->qa == 5 * 64 && c->qb == 11 * 64)
-        hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false, 5, 11>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->d_qtab, c->qa, c->qb, tot, c->W, c->H, c->max_kp);
+    if (GFMT == sift::GRAD_PACKED16 && (int)grid.x == c->max_kp && c->qa == 5 * 64 && c->qu == 9 * 64 && c->qb == 2 * 64)
+        hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false, 5, 9, 2>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->d_qtab, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp);
     else if ((int)grid.x == c->max_kp)
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->d_qtab, c->qa, c->qb, tot, c->W, c->H, c->max_kp);
-    else if (GFMT == sift::GRAD_PACKED16 && c->qa == 5 * 64 && c->qb == 11 * 64)
-        hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true, 5, 11>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->d_qtab, c->qa, c->qb, tot, c->W, c->H, c->max_kp);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->d_qtab, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp);
+    else if (GFMT == sift::GRAD_PACKED16 && c->qa == 5 * 64 && c->qu == 9 * 64 && c->qb == 2 * 64)
+        hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true, 5, 9, 2>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->d_qtab, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp);
     else
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->d_qtab, c->qa, c->qb, tot, c->W, c->H, c->max_kp);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->d_qtab, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp);
     HIP_TRY(hipGetLastError());
     return SIFT_HIP_OK;
 }
@@ -472,10 +491,10 @@ int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int m
     A((void **)&c->d_ori, B * (size_t)max_keypoints);
     A((void **)&c->d_tab, tab.size() * sizeof(uint2));
     c->ntab = (int)tab.size(); c->n2 = wt.n2; c->n2pad = wt.n2pad;
-    c->qa = qt.qa; c->qb = qt.qb;
+    c->qa = qt.qa; c->qu = qt.qu; c->qb = qt.qb;
     if (const char *v = getenv("SIFT_HIP_GRAPH_FRAMES")) c->graph_max_frames = std::max(0, atoi(v));   // tuning knob
-    A((void **)&c->d_qtab, qt.words.size() * 4);
-    if (e == hipSuccess) e = hipMemcpy(c->d_qtab, qt.words.data(), qt.words.size() * 4, hipMemcpyHostToDevice);
+    A((void **)&c->d_qtab, qt.bytes.size());
+    if (e == hipSuccess) e = hipMemcpy(c->d_qtab, qt.bytes.data(), qt.bytes.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_tab, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         sift_hip_destroy(c);
