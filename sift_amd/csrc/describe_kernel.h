@@ -23,11 +23,11 @@
 //
 // Lanes l and l+32 accumulate into LDS column l of hist[row][32] (bank =
 // column: no conflicts inside a half wave; ds_add_u32 without return).
-//   * internal gradient format (k_detect's 2-byte plane, gradp_pack): one word
-//     is mag | (a>>1) << 9 | (a&1) << 15 with a = code-1, and 0 for code 0, so
+//   * internal gradient format (k_detect's 2-byte plane, detect_kernel.h: gradp_pack): a pixel
+//     carries mag, dir = a >> 1 and b = a & 1 with a = code-1, all 0 for code 0, so
 //     every pixel is added without a test (code 0 is accumulated and then discarded by the
 //     reference, :245-252).  Two direction bins share a dword as 16-bit
-//     halves: row = circle*4 + (a>>1), half = a&1 (40 rows, 5 KB per wave).
+//     halves: row = circle*4 + dir, half = b (40 rows, 5 KB per wave).
 //     A half holds at most 2 lanes x 61 pixels x 360 < 2^16.
 //   * caller-supplied Grad_t planes (the stand-alone entry points): a bin is a
 //     full dword, row = circle*8 + a (80 rows); codes outside 1..8 are dropped.
@@ -48,9 +48,11 @@
 //   hi = 4 x (c1 | c2 << 4), one byte per pixel of the quad
 // with circle id 9 = the overlap bins and 10, 11 = "not in the union" / "not an
 // overlap pixel" (eight spare LDS rows that are never read), so every pixel of a quad is added without a
-// test.  Quads with a two-circle pixel come first (3 adds per pixel), then the
-// rest (1 add per pixel); both lists are padded to multiples of 64 with quads
-// that only feed the spare rows.
+// test.  Quads with a two-circle pixel come first (part A, 3 adds per pixel),
+// then the quads whose four pixels lie in one circle (part U, 2-byte entries, the
+// circle's LDS offset formed once per quad), then the rest (part B, 1 add per
+// pixel); A and B are padded to multiples of 64 with quads that only feed the
+// spare rows, U holds whole steps only.
 //
 // The gradient plane is addressed linearly like the reference does
 // (pGrad[y*WIDTH + x - 35 + col], :64/:204); indices outside the plane read
