@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-overlap"   # the plain one-stream loop that `value` and the roofline are measured on
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH --steps 20 --warmup 3 > "$OUT/trace.json" 2> "$OUT/trace.err" || { echo "trace pass failed"; tail -5 "$OUT/trace.err"; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $BENCH --steps 2 --warmup 1 --no-profile-events > "$OUT/fetch.json" 2> "$OUT/fetch.err" || { echo "fetch pass failed"; tail -5 "$OUT/fetch.err"; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $BENCH --steps 2 --warmup 1 --no-profile-events > "$OUT/write.json" 2> "$OUT/write.err" || { echo "write pass failed"; tail -5 "$OUT/write.err"; exit 1; }
