@@ -16,17 +16,18 @@ namespace sift {
 
 struct kp_t { uint16_t x, y; uint32_t contrast; };   // Keypoint_t, SIFTParameters.hpp:79-85
 
-// bits [x0, x0+7) of row mask `m` (S segments), out-of-range bits read 0.  Branch-free: both
-// segments are always loaded (from clamped addresses), so calls for several rows overlap.
+// bits [x0, x0+7) of row mask `m` (S segments), out-of-range bits read 0.  Branch-free: one
+// unaligned 2-byte load from a clamped byte offset (the mask is little-endian, so bit b of the
+// row is bit b & 7 of byte b >> 3); bits left of the row are shifted in as zeros, bits right of
+// it shifted out of the 16 loaded ones.  Calls for several rows overlap.
 __device__ __forceinline__ uint32_t mask_field7(const u64 *__restrict__ m, int S, int x0)
 {
-    const int sa = x0 >> 6;                          // -1 for x0 in [-3, -1]
-    const int off = x0 & 63;
-    const bool va = sa >= 0 && sa < S, vb = sa + 1 >= 0 && sa + 1 < S;
-    const u64 a = m[va ? sa : 0], b = m[vb ? sa + 1 : 0];
-    u64 f = (va ? a : 0ull) >> off;
-    f |= off ? ((vb ? b : 0ull) << (64 - off)) : 0ull;
-    return (uint32_t)(f & 0x7full);
+    const int bo = min(max(x0 >> 3, 0), S * 8 - 2);  // x0 in [-3, 64 S + 2]
+    const int sh = x0 - bo * 8;                      // -3 .. 18
+    uint16_t v16;
+    __builtin_memcpy(&v16, reinterpret_cast<const char *>(m) + bo, 2);
+    const uint32_t v = v16;
+    return (sh >= 0 ? v >> sh : v << -sh) & 0x7fu;
 }
 
 // (:393) keep only 71 < y < H-71 and 71 < x < W-71
@@ -73,12 +74,21 @@ __global__ __launch_bounds__(256) void k_cull(const u64 *__restrict__ candmask, 
             nb |= (u64)(ok ? f : 0u) << (7 * (dy + 3));
         }
         nb &= ~(1ull << 24);                                         // not the keypoint itself (:728)
+        // the neighbours' keys, four loads in flight (a lane rarely has more neighbours)
         bool best = true;
         while (nb && best) {
-            const int k = __ffsll((long long)nb) - 1;
-            nb &= nb - 1;
-            const uint32_t en = kp[(size_t)(y + k / 7 - 3) * W + (x + k % 7 - 3)] >> 8;
-            if (!(ec < en)) best = false;                            // strict (:730)
+            uint32_t en[4];
+            bool has[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                has[u] = nb != 0ull;
+                const int k = has[u] ? __ffsll((long long)nb) - 1 : 24;   // 24: the keypoint itself
+                nb &= nb - 1;
+                en[u] = kp[(size_t)(y + k / 7 - 3) * W + (x + k % 7 - 3)] >> 8;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (has[u] && !(ec < en[u])) best = false;           // strict (:730)
         }
         if (best) {
             const u64 bit = 1ull << (x & 63);
@@ -98,19 +108,34 @@ __global__ __launch_bounds__(256) void k_emit(const u64 *__restrict__ survmask,
                                               uint32_t *__restrict__ total_ctx, uint32_t *__restrict__ total_out,
                                               int W, int H, int S, int max_kp)
 {
-    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (y > H) return;
+    __shared__ uint32_t part[4];
+    const int y0 = blockIdx.x * 4, wave = threadIdx.x >> 6;
+    const int y = y0 + wave;
     const int lane = threadIdx.x & 63;
     const size_t frow = (size_t)blockIdx.y * H;
     const uint32_t *__restrict__ rc = rowcount + frow;
     kp_t *__restrict__ out = kps + (size_t)blockIdx.y * max_kp;
 
-    if (y < H && rc[y] == 0) return;                 // nothing to emit from this row
-    // keypoints in rows above (y == H: the frame total)
+    // the row's own count and its first 64 mask segments are requested together with the counts
+    // of the rows above, so that the wave waits for memory once before it reads the keys
+    uint32_t own = 0;
+    u64 m0 = 0ull;
+    if (y < H) {
+        own = rc[y];
+        if (lane < S) m0 = survmask[(frow + y) * S + lane];
+    }
+    // keypoints in the rows above the block's four: summed once by the whole block
     uint32_t base = 0;
-    for (int r = lane; r < y; r += 64) base += rc[r];
+    for (int r = threadIdx.x; r < min(y0, H); r += 256) base += rc[r];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) base += __shfl_xor(base, o);
+    if (lane == 0) part[wave] = base;
+    __syncthreads();
+    if (y > H) return;
+    if (y < H && own == 0) return;                   // nothing to emit from this row
+    // keypoints in rows above (y == H: the frame total)
+    base = part[0] + part[1] + part[2] + part[3];
+    for (int r = y0; r < y; r++) base += rc[r];      // r < y <= H
 
     if (y == H) {
         // padding (:428-436) and the uncapped total (nKeypointsTotal, :405-406)
@@ -129,7 +154,7 @@ __global__ __launch_bounds__(256) void k_emit(const u64 *__restrict__ survmask,
     for (int s0 = 0; s0 < S; s0 += 64) {
         const int seg = s0 + lane;
         u64 m = 0ull;
-        if (seg < S) m = survmask[(frow + y) * S + seg] & border_mask(y, seg, W, H);
+        if (seg < S) m = (s0 == 0 ? m0 : survmask[(frow + y) * S + seg]) & border_mask(y, seg, W, H);
         const uint32_t n = (uint32_t)__popcll(m);
         // inclusive wave scan of n
         uint32_t inc = n;
