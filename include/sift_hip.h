@@ -201,6 +201,10 @@ int sift_hip_set_blur_rows(sift_hip_ctx *ctx, int rows);
 /* Tuning knob: sift_hip_detect_and_compute_dev calls of up to `max_frames` frames (default 4) that
  * repeat the previous call's buffers and parameters are replayed as one HIP graph; 0 = never. */
 int sift_hip_set_graph_frames(sift_hip_ctx *ctx, int max_frames);
+/* Test knob: on = 0 sends every descriptor window of sift_hip_detect_and_compute[_dev] through the
+ * pixel-by-pixel sweep that otherwise only serves windows the quad sweep cannot take (none that
+ * sift_detect emits); results are identical, the kernel is several times slower.  Default: on. */
+int sift_hip_set_quad_sweep(sift_hip_ctx *ctx, int on);
 /* Tuning knob: rows per strip of the detect kernel (0 = heuristic; clamped to [4, 32]). */
 int sift_hip_set_detect_rows(sift_hip_ctx *ctx, int rows);
 

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
         // quad sweep: the 19 aligned quads per row that cover the window must lie in their rows
         const int x0 = px - 35, y0 = py - 35;
         const int xph = x0 & 3, yph = y0 & 3;        // one table per alignment of the window in the plane
-        if (x0 - xph >= 0 && x0 - xph + 76 <= W && y0 >= 0 && py + 35 < H) {
+        if (qtab && x0 - xph >= 0 && x0 - xph + 76 <= W && y0 >= 0 && py + 35 < H) {
             const char *gq = gplane + gradp_quad_word(y0 - yph, (x0 - xph) >> 2, W4) * 2;
             const char *tq = reinterpret_cast<const char *>(qtab) + (size_t)(yph * 4 + xph) * ((size_t)qa * 8u + (size_t)qu * 2u + (size_t)qb * 4u);
             if constexpr (NA + NU + NB > 0) quad_static(gq, tq);

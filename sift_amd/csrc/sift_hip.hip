@@ -231,6 +231,7 @@ struct sift_hip_ctx {
     uint2 *d_tab = nullptr;
     uint32_t *d_qtab = nullptr;           // quad table (build_quad_table)
     int ntab = 0, n2 = 0, n2pad = 0, qa = 0, qu = 0, qb = 0;
+    bool quad_sweep = true;               // false: every window through the pixel sweep (sift_hip_set_quad_sweep)
     int blur_rows = 0;
     // graph of the last fused call (small batches: launch gaps are a third of a single frame's time)
     struct GraphKey { const void *imgs = nullptr, *kps = nullptr, *desc = nullptr, *total = nullptr; int nframes = 0, th = 0, brows = 0, drows = 0; } gkey;
@@ -372,16 +373,16 @@ int run_describe(sift_hip_ctx *c, const void *d_grad, int nframes, const sift::k
     // the reference's masks give 5 + 11 steps of 64 quads: straight-line variant
     if (GFMT == sift::GRAD_PACKED16 && (int)grid.x == c->max_kp && c->qa == 5 * 64 && c->qu == 9 * 64 && c->qb == 2 * 64)
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false, 5, 9, 2>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->d_qtab, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp);
     else if ((int)grid.x == c->max_kp)
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->d_qtab, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp);
     else if (GFMT == sift::GRAD_PACKED16 && c->qa == 5 * 64 && c->qu == 9 * 64 && c->qb == 2 * 64)
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true, 5, 9, 2>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->d_qtab, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp);
     else
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->d_qtab, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp);
     HIP_TRY(hipGetLastError());
     return SIFT_HIP_OK;
 }
@@ -560,6 +561,16 @@ int sift_hip_set_graph_frames(sift_hip_ctx *c, int max_frames)
     if (int r = check_ctx(c)) return r;
     if (max_frames < 0) return fail(SIFT_HIP_EINVAL, "max_frames must be >= 0");
     c->graph_max_frames = max_frames;
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_set_quad_sweep(sift_hip_ctx *c, int on)
+{
+    if (int r = check_ctx(c)) return r;
+    c->quad_sweep = on != 0;
+    if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }   // a captured graph holds the old choice
+    c->gkey = sift_hip_ctx::GraphKey{};
+    c->gseen = 0;
     return SIFT_HIP_OK;
 }
 

@@ -176,6 +176,10 @@ class SiftContext:
     def set_graph_frames(self, max_frames):
         check(self._lib.sift_hip_set_graph_frames(self._h, int(max_frames)))
 
+    def set_quad_sweep(self, on):
+        """test knob: False sends every descriptor window through the pixel-by-pixel sweep"""
+        check(self._lib.sift_hip_set_quad_sweep(self._h, 1 if on else 0))
+
     def set_detect_rows(self, rows):
         check(self._lib.sift_hip_set_detect_rows(self._h, int(rows)))
 

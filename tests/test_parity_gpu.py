@@ -273,6 +273,25 @@ def test_strip_lengths_do_not_change_results(sift, orc):
             assert (kps2 == rk).all() and (grad["ang"] == rg["ang"]).all() and (grad["mag"] == rg["mag"]).all()
 
 
+def test_pixel_sweep_of_the_internal_gradient_plane(sift, orc):
+    """The fused path reads its interleaved pair-dword gradient plane through the quad tables; the
+    pixel-by-pixel sweep of the same plane (the fallback for windows the quad sweep cannot take, none
+    that sift_detect emits) is forced here and must give the same bits."""
+    for W, H, seed in ((640, 480, 9), (324, 201, 3), (260, 1000, 4)):
+        img = orc.synth_frame(seed, W, H)
+        rk, rd, _ = orc.detect_and_compute(img)
+        n = nvalid(rk)
+        assert n > 0
+        with sift.SiftContext(W, H) as ctx:
+            ctx.set_quad_sweep(False)
+            for _ in range(4):                                      # also across the graph replay threshold
+                kps, desc = ctx.sift_detect_and_compute(img)
+                assert (kps == rk).all() and (desc[:n] == rd[:n]).all(), (W, H)
+            ctx.set_quad_sweep(True)
+            kps, desc = ctx.sift_detect_and_compute(img)
+            assert (kps == rk).all() and (desc[:n] == rd[:n]).all(), (W, H)
+
+
 def test_graph_replay_of_repeated_small_calls(sift, orc):
     """Calls of a few frames that repeat the previous call are replayed as one HIP graph: same bits as
     kernel-by-kernel launches, also after the frame changed in place, after a switch of buffers, with
