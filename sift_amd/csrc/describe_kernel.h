@@ -86,6 +86,43 @@ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)   // v_pk_add
     return __builtin_bit_cast(uint32_t, r);
 }
 
+// Caller-supplied Grad_t planes (the stand-alone entry points) into the internal plane, so that
+// those calls take the quad sweep too.  The internal format holds magnitudes up to
+// DESC_MAX_MAG_PACKED in 16-bit bin halves; a larger one (sift_detect produces none) raises
+// *flag, and the call then runs the Grad_t kernel instead.  Codes outside 1..8 carry no weight
+// (:245-252), like code 0.
+// grid: x = ceil(W/4 / 256), y = ceil(H/4) groups of rows, z = frames; block = 256
+__global__ __launch_bounds__(256) void k_grad_pairs(const uint4 *__restrict__ grad, uint16_t *__restrict__ gradp,
+                                                    uint32_t *__restrict__ flag, int W, int H)
+{
+    const int W4 = W >> 2, g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= W4) return;
+    const uint4 *__restrict__ fin = grad + (size_t)blockIdx.z * (size_t)W4 * (size_t)H;
+    uint32_t o[8];
+    bool big = false;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int y = blockIdx.y * 4 + r;
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (y < H) q = fin[(size_t)y * W4 + g];
+        const uint32_t px[4] = {q.x, q.y, q.z, q.w};
+        uint32_t w[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const uint32_t ang = px[p] & 0xffffu, mag = px[p] >> 16;
+            const bool counts = ang >= 1u && ang <= 8u;
+            big |= counts && mag > (uint32_t)DESC_MAX_MAG_PACKED;
+            w[p] = counts ? gradp_pack((int)ang, (int)(mag & 0x1ffu), p & 1) : 0u;
+        }
+        o[2 * r] = w[0] | w[1];
+        o[2 * r + 1] = w[2] | w[3];
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(gradp + gradp_frame_words(W, H) * (size_t)blockIdx.z + gradp_quad_word(blockIdx.y * 4, g, W4));
+    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    if (big) atomicOr(flag, 1u);
+}
+
 // grid: x = max_kp keypoints, y = frames; block = 64 (one wave)
 // NA, NU, NB > 0: the quad table has exactly NA, NU and NB steps of 64 quads (the reference's masks:
 // 5, 9 and 2) and the sweep is straight-line code with every load of the window in flight at once
@@ -95,8 +132,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
                                                  uint32_t *__restrict__ desc, const uint2 *__restrict__ tab,
                                                  int n2, int n2pad, int ntab, const void *__restrict__ qtab,
                                                  int qa, int qu, int qb, const uint32_t *__restrict__ total, int W, int H,
-                                                 int max_kp)
+                                                 int max_kp, const uint32_t *__restrict__ gate, uint32_t gate_want)
 {
+    // stand-alone calls launch this kernel once per gradient format; k_grad_pairs' flag says which runs
+    if (gate && *gate != gate_want) return;
     constexpr bool PACK = GFMT == GRAD_PACKED16;
     constexpr int ROWS = PACK ? 40 : 80;         // rows that hold bins
     constexpr int LROWS = PACK ? 48 : 80;        // + circle id 10: spare rows of the quad sweep (never read)

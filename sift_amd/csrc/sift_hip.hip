@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <optional>
 #include <vector>
 #include <thread>
 #include <algorithm>
@@ -230,6 +231,7 @@ struct sift_hip_ctx {
     size_t bgr_cap = 0;
     uint2 *d_tab = nullptr;
     uint32_t *d_qtab = nullptr;           // quad table (build_quad_table)
+    uint32_t *d_gate = nullptr;           // k_grad_pairs' flag: which of the two describe kernels of a stand-alone call runs
     int ntab = 0, n2 = 0, n2pad = 0, qa = 0, qu = 0, qb = 0;
     bool quad_sweep = true;               // false: every window through the pixel sweep (sift_hip_set_quad_sweep)
     int blur_rows = 0;
@@ -361,9 +363,10 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
 
 template <int GFMT, int MODE>
 int run_describe(sift_hip_ctx *c, const void *d_grad, int nframes, const sift::kp_t *d_kps, const uint8_t *ori_in,
-                 uint8_t *ori_out, uint32_t *d_desc, hipStream_t s)
+                 uint8_t *ori_out, uint32_t *d_desc, hipStream_t s, const uint32_t *gate = nullptr, uint32_t gate_want = 0)
 {
-    StageTimer t(c, ST_DESCRIBE, s);
+    std::optional<StageTimer> t;
+    if (!gate) t.emplace(c, ST_DESCRIBE, s);         // gated pairs are timed as one by run_describe_planes
     // one wave per slot, or per group of slots when the batch is so large that the launch would
     // exceed ~650k waves (sparse frames: most of them would only write zeros)
     const bool fused = MODE == sift::DESC_FUSED;
@@ -373,18 +376,35 @@ int run_describe(sift_hip_ctx *c, const void *d_grad, int nframes, const sift::k
     // the reference's masks give 5 + 11 steps of 64 quads: straight-line variant
     if (GFMT == sift::GRAD_PACKED16 && (int)grid.x == c->max_kp && c->qa == 5 * 64 && c->qu == 9 * 64 && c->qb == 2 * 64)
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false, 5, 9, 2>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want);
     else if ((int)grid.x == c->max_kp)
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want);
     else if (GFMT == sift::GRAD_PACKED16 && c->qa == 5 * 64 && c->qu == 9 * 64 && c->qb == 2 * 64)
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true, 5, 9, 2>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want);
     else
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want);
     HIP_TRY(hipGetLastError());
     return SIFT_HIP_OK;
+}
+
+// Stand-alone orientation / descriptor calls: the caller's Grad_t planes are rewritten into the
+// internal plane (a streaming kernel) and swept by the fast kernel; if a magnitude does not fit
+// that format the flag set by the conversion lets the Grad_t kernel run instead.  Both kernels are
+// enqueued, one of them returns at once.
+template <int MODE>
+int run_describe_planes(sift_hip_ctx *c, const sift_grad *d_grad, int nframes, const sift::kp_t *d_kps, const uint8_t *ori_in,
+                        uint8_t *ori_out, uint32_t *d_desc, hipStream_t s)
+{
+    StageTimer t(c, ST_DESCRIBE, s);
+    HIP_TRY(hipMemsetAsync(c->d_gate, 0, 4, s));
+    const dim3 grid((c->W / 4 + 255) / 256, (c->H + 3) / 4, nframes);
+    hipLaunchKernelGGL(sift::k_grad_pairs, grid, dim3(256), 0, s, (const uint4 *)d_grad, c->d_gradp, c->d_gate, c->W, c->H);
+    HIP_TRY(hipGetLastError());
+    if (int r = run_describe<sift::GRAD_PACKED16, MODE>(c, c->d_gradp, nframes, d_kps, ori_in, ori_out, d_desc, s, c->d_gate, 0u)) return r;
+    return run_describe<sift::GRAD_FULL32, MODE>(c, d_grad, nframes, d_kps, ori_in, ori_out, d_desc, s, c->d_gate, 1u);
 }
 
 int check_ctx(const sift_hip_ctx *c)
@@ -494,6 +514,7 @@ int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int m
     c->ntab = (int)tab.size(); c->n2 = wt.n2; c->n2pad = wt.n2pad;
     c->qa = qt.qa; c->qu = qt.qu; c->qb = qt.qb;
     if (const char *v = getenv("SIFT_HIP_GRAPH_FRAMES")) c->graph_max_frames = std::max(0, atoi(v));   // tuning knob
+    A((void **)&c->d_gate, 4);
     A((void **)&c->d_qtab, qt.bytes.size());
     if (e == hipSuccess) e = hipMemcpy(c->d_qtab, qt.bytes.data(), qt.bytes.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_tab, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice);
@@ -511,7 +532,7 @@ void sift_hip_destroy(sift_hip_ctx *c)
     DevGuard g(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_img, c->d_pyr, c->d_zero, c->d_list, c->d_listcount, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_gradp,
-                    c->d_gradfull, c->d_final, c->d_findex, c->d_nvalid, c->d_tfinal, c->d_tindex, c->d_tdesc, c->d_tnvalid, c->d_bgr, c->d_kps, c->d_desc, c->d_total, c->d_total_ctx, c->d_ori, c->d_tab, c->d_qtab};
+                    c->d_gradfull, c->d_final, c->d_findex, c->d_nvalid, c->d_tfinal, c->d_tindex, c->d_tdesc, c->d_tnvalid, c->d_bgr, c->d_kps, c->d_desc, c->d_total, c->d_total_ctx, c->d_ori, c->d_tab, c->d_qtab, c->d_gate};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &ps : c->prof)
         for (int i = 0; i < SIFT_HIP_NSTAGES; i++)
@@ -670,8 +691,7 @@ int sift_hip_main_orientation_dev(sift_hip_ctx *c, const sift_grad *d_grad, int 
     DevGuard g(c->device);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     begin_call(c);
-    return run_describe<sift::GRAD_FULL32, sift::DESC_ORI_ONLY>(c, d_grad, nframes, (const sift::kp_t *)d_kps, nullptr,
-                                                                d_ori, nullptr, s);
+    return run_describe_planes<sift::DESC_ORI_ONLY>(c, d_grad, nframes, (const sift::kp_t *)d_kps, nullptr, d_ori, nullptr, s);
 }
 
 int sift_hip_descriptor_dev(sift_hip_ctx *c, const sift_grad *d_grad, int nframes, const sift_keypoint *d_kps,
@@ -683,8 +703,7 @@ int sift_hip_descriptor_dev(sift_hip_ctx *c, const sift_grad *d_grad, int nframe
     DevGuard g(c->device);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     begin_call(c);
-    return run_describe<sift::GRAD_FULL32, sift::DESC_GIVEN_ORI>(c, d_grad, nframes, (const sift::kp_t *)d_kps, d_ori,
-                                                                 nullptr, d_desc, s);
+    return run_describe_planes<sift::DESC_GIVEN_ORI>(c, d_grad, nframes, (const sift::kp_t *)d_kps, d_ori, nullptr, d_desc, s);
 }
 
 int sift_hip_select_top_dev(sift_hip_ctx *c, const sift_keypoint *d_kps, int nframes, int nfinal, sift_keypoint *d_final,

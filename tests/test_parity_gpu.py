@@ -173,6 +173,39 @@ def test_caller_supplied_keypoints_near_edges(sift, orc):
             assert (d == orc.descriptor(grad, kps, o)).all()
 
 
+def test_caller_supplied_gradient_planes(sift, orc):
+    """The stand-alone calls take ANY Grad_t plane.  Planes that fit the internal format (magnitudes
+    up to 360, what sift_detect produces) are rewritten into it and swept by the fast kernel; a
+    plane with a larger magnitude makes the same call run the Grad_t kernel.  Codes outside 1..8
+    carry no weight in either (SIFT_Descriptor.cpp:245-252)."""
+    W, H = 320, 240
+    rng = np.random.default_rng(11)
+    kps = np.zeros(10000, sift.KP_DTYPE)
+    n = 500
+    kps["x"][:n] = rng.integers(0, W, n)
+    kps["y"][:n] = rng.integers(0, H, n)
+    kps["contrast"][:n] = rng.integers(1, 200, n)
+    with sift.SiftContext(W, H) as ctx:
+        for maxmag, maxang in ((360, 8), (360, 12), (361, 8), (32767, 8), (32767, 40), (1, 8)):
+            grad = np.zeros((H, W), sift.GRAD_DTYPE)
+            grad["ang"] = rng.integers(0, maxang + 1, (H, W))
+            grad["mag"] = rng.integers(0, maxmag + 1, (H, W))
+            grad["mag"][rng.integers(0, H), rng.integers(0, W)] = maxmag      # the bound is reached
+            grad["ang"][grad["mag"] == maxmag] = 3
+            ori = ctx.compute_main_orientation(grad, kps)
+            ro = orc.main_orientation(grad, kps)
+            assert (ori == ro).all(), (maxmag, maxang)
+            d = ctx.compute_descriptor(grad, kps, ro)
+            assert (d == orc.descriptor(grad, kps, ro)).all(), (maxmag, maxang)
+        # worst case for the 16-bit bin halves of the fast kernel: every pixel 360, one direction
+        grad = np.zeros((H, W), sift.GRAD_DTYPE)
+        grad["ang"] = 2
+        grad["mag"] = 360
+        ro = orc.main_orientation(grad, kps)
+        assert (ctx.compute_main_orientation(grad, kps) == ro).all()
+        assert (ctx.compute_descriptor(grad, kps, ro) == orc.descriptor(grad, kps, ro)).all()
+
+
 def test_batched_device_entry_points(sift, orc):
     """cfg 4 shape: several frames per launch, inputs and outputs resident in HBM."""
     import torch
