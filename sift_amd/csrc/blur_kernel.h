@@ -317,18 +317,17 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, 
         for (int p = 0; p < NP; p++) a1[s][p] = 0;
     uint32_t d1[7] = {0, 0, 0, 0, 0, 0, 0}, d2[4] = {0, 0, 0, 0};
 
-    uint32_t cur[7], nxt[7];
-    load_row(ys - 9, cur);
+    // c[]: the masked dwords of the current row; the next row is loaded one iteration ahead and
+    // masked into c[] at the bottom (the masking doubles as the hand-over: no register copies)
+    uint32_t c[7], nxt[7];
+    load_row(ys - 9, nxt);
+#pragma unroll
+    for (int k = 0; k < 7; k++) c[k] = nxt[k] & cm[k];
     for (int i = ys - 9; i < ye + 9; ++i) {
-        load_row(i + 1, nxt);                 // prefetch: consumed in the next iteration
+        load_row(i + 1, nxt);                 // prefetch: consumed at the bottom
         // source dword of the row that finishes in this iteration (used at the bottom)
         const int y3 = i - 9;
         const uint32_t sp = *reinterpret_cast<const uint32_t *>(row_ptr(y3) + qc[3]);
-
-        // window dwords: pixel p's window starts at byte 3+p of cur[]
-        uint32_t c[7];
-#pragma unroll
-        for (int k = 0; k < 7; k++) c[k] = cur[k] & cm[k];
         uint32_t w[4][5];
 #pragma unroll
         for (int j = 0; j < 5; j++) {
@@ -374,7 +373,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, 
         d2[0] = pack4_q15(a2[0]);
 
 #pragma unroll
-        for (int k = 0; k < 7; k++) cur[k] = nxt[k];
+        for (int k = 0; k < 7; k++) c[k] = nxt[k] & cm[k];
     }
 }
 
