@@ -292,9 +292,13 @@ int pick_blur_rows(const sift_hip_ctx *c, int nframes)
         if (rows < 6) break;
         const double strips = (double)((c->H + rows - 1) / rows);
         const double waves = waves_per_strip * strips * nframes;
-        const double per_wave = rows >= c->blur_sym_rows ? 0.66 * (rows + 18) : rows + 9.0;
+        // long strips run a little slower per row (measured with tools/blur_rows_big.py: 1080-row
+        // strips 4 % behind 360-row ones although they have the smallest warm-up share)
+        const double per_wave = rows >= c->blur_sym_rows ? 0.66 * (rows + 18) * (1.0 + rows / 10000.0) : rows + 9.0;
         const double full = std::floor(waves / 2048.0), rem = waves - 2048.0 * full;
-        const double cost = per_wave * (1.5 * full + (rem <= 0.0 ? 0.0 : rem <= 1024.0 ? 1.0 : 1.5));
+        // more than four rounds of 2048 waves: the rounds blur into a steady stream
+        const double cost = per_wave * (waves > 4.0 * 2048.0 ? 1.5 * waves / 2048.0
+                                                             : 1.5 * full + (rem <= 0.0 ? 0.0 : rem <= 1024.0 ? 1.0 : 1.5));
         if (cost < best * 0.999) { best = cost; best_rows = rows; }
     }
     return best_rows;
