@@ -371,3 +371,31 @@ def test_graph_replay_of_repeated_small_calls(sift, orc):
         for rep in range(5):
             kps, desc = ctx.sift_detect_and_compute(imgs[1])
             assert (kps == ref[1][0]).all()
+
+
+def test_bench_line_contract(sift):
+    """bench.py prints one JSON line with the keys the driver reads, the roofline of the dominant
+    kernel and the CPU baseline (small frames and few steps here; the default run is 1080p)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--width", "640", "--height", "480", "--batch", "8",
+                        "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=110, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "frames/s"
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "u8" and d["data"] == "synthetic"
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] * 1e-3 - 8) < 1e-6 * 8 + 1e-9
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0 and cb["sample"]
+    assert d["overlapped"]["outputs_equal_one_stream"] is True
