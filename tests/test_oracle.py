@@ -353,3 +353,22 @@ def test_synth_generator_numpy_equals_c(orc):
     import sift_amd
     for seed, W, H in ((1, 64, 48), (7, 100, 37), (123456789, 256, 256)):
         assert (sift_amd.synth_frame(seed, W, H) == orc.synth_frame(seed, W, H)).all()
+
+
+@pytest.mark.parametrize("dx,dy", [(5, 3), (2, 1)])
+def test_oracle_translation_covariance(orc, dx, dy):
+    """The same property the GPU test checks at 1080p: content moved by (dx, dy) gives the keypoints
+    moved by (dx, dy) with the same contrasts and descriptors (every stage is local; zero padding
+    reaches 41 pixels into the frame, keypoints are kept beyond 71)."""
+    W, H = 640, 480
+    a = orc.synth_frame(77, W, H)
+    b = np.zeros_like(a)
+    b[dy:, dx:] = a[:H - dy, :W - dx]
+    ka, da, _ = orc.detect_and_compute(a)
+    kb, db, _ = orc.detect_and_compute(b)
+    na, nb = int((ka["contrast"] > 0).sum()), int((kb["contrast"] > 0).sum())
+    ia = np.array([i for i in range(na) if ka["x"][i] < W - 71 - dx and ka["y"][i] < H - 71 - dy])
+    ib = np.array([i for i in range(nb) if kb["x"][i] > 71 + dx and kb["y"][i] > 71 + dy])
+    assert len(ia) == len(ib) > 300
+    assert (ka["x"][ia] + dx == kb["x"][ib]).all() and (ka["y"][ia] + dy == kb["y"][ib]).all()
+    assert (ka["contrast"][ia] == kb["contrast"][ib]).all() and (da[ia] == db[ib]).all()

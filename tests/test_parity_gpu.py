@@ -399,3 +399,29 @@ def test_bench_line_contract(sift):
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0 and cb["sample"]
     assert d["overlapped"]["outputs_equal_one_stream"] is True
+
+
+@pytest.mark.parametrize("dx,dy", [(5, 3), (2, 1), (3, 6)])
+def test_translation_covariance_at_full_size(sift, dx, dy):
+    """A property that needs no oracle, at BASELINE's full size: every stage is local (zero padding
+    only matters within 41 pixels of the frame edge, keypoints are kept only beyond 71), so a frame
+    whose content is moved by (dx, dy) gives the same keypoints moved by (dx, dy), with the same
+    contrasts and the same descriptors.  The moves change the alignment of every window in the
+    gradient plane, so all variants of the descriptor tables are compared with each other."""
+    from sift_amd.synth import synth_frame
+    W, H = 1920, 1080
+    a = synth_frame(77, W, H)
+    b = np.zeros_like(a)
+    b[dy:, dx:] = a[:H - dy, :W - dx]
+    with sift.SiftContext(W, H) as ctx:
+        ka, da = ctx.sift_detect_and_compute(a)
+        kb, db = ctx.sift_detect_and_compute(b)
+    na, nb = nvalid(ka), nvalid(kb)
+    assert 0 < na < 10000 and 0 < nb < 10000                      # the cap would cut the two lists differently
+    ia = [i for i in range(na) if ka["x"][i] < W - 71 - dx and ka["y"][i] < H - 71 - dy]
+    ib = [i for i in range(nb) if kb["x"][i] > 71 + dx and kb["y"][i] > 71 + dy]
+    assert len(ia) == len(ib) > 5000
+    ia, ib = np.array(ia), np.array(ib)
+    assert (ka["x"][ia] + dx == kb["x"][ib]).all() and (ka["y"][ia] + dy == kb["y"][ib]).all()
+    assert (ka["contrast"][ia] == kb["contrast"][ib]).all()
+    assert (da[ia] == db[ib]).all()
