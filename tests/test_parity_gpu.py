@@ -425,3 +425,33 @@ def test_translation_covariance_at_full_size(sift, dx, dy):
     assert (ka["x"][ia] + dx == kb["x"][ib]).all() and (ka["y"][ia] + dy == kb["y"][ib]).all()
     assert (ka["contrast"][ia] == kb["contrast"][ib]).all()
     assert (da[ia] == db[ib]).all()
+
+
+@pytest.mark.parametrize("flip", ["lr", "ud", "both"])
+def test_mirror_symmetry_of_detection_at_full_size(sift, flip):
+    """Second oracle-free property at full size: the blur tables are symmetric under both flips, the
+    extremum, contrast, edge and 7x7 tests have no preferred direction and all four borders read 0, so
+    a mirrored frame gives the mirrored keypoint set with the same contrasts (positions whose mirror
+    image falls on the other side of the 71-pixel border rule are left out)."""
+    from sift_amd.synth import synth_frame
+    W, H = 1920, 1080
+    a = synth_frame(78, W, H)
+    b = a[:, ::-1] if flip == "lr" else a[::-1, :] if flip == "ud" else a[::-1, ::-1]
+    b = np.ascontiguousarray(b)
+    with sift.SiftContext(W, H) as ctx:
+        ka, _ = ctx.sift_detect_and_compute(a)
+        kb, _ = ctx.sift_detect_and_compute(b)
+    na, nb = nvalid(ka), nvalid(kb)
+    assert 0 < na < 10000 and 0 < nb < 10000
+
+    def keyset(k, n, mirror):
+        out = set()
+        for x, y, c in zip(k["x"][:n].tolist(), k["y"][:n].tolist(), k["contrast"][:n].tolist()):
+            if mirror:
+                x = W - 1 - x if flip in ("lr", "both") else x
+                y = H - 1 - y if flip in ("ud", "both") else y
+            if 72 < x < W - 73 and 72 < y < H - 73:
+                out.add((x, y, c))
+        return out
+    sa, sb = keyset(ka, na, False), keyset(kb, nb, True)
+    assert sa == sb and len(sa) > 5000
