@@ -377,7 +377,7 @@ int run_describe(sift_hip_ctx *c, const void *d_grad, int nframes, const sift::k
     const int gx = std::max(1024, std::min(c->max_kp, (655360 + nframes - 1) / nframes));
     dim3 grid(std::min(gx, c->max_kp), nframes);
     const uint32_t *tot = fused ? (const uint32_t *)c->d_total_ctx : (const uint32_t *)nullptr;
-    // the reference's masks give 5 + 11 steps of 64 quads: straight-line variant
+    // the reference's masks give 5 + 9 + 2 steps of 64 quads: straight-line variant
     if (GFMT == sift::GRAD_PACKED16 && (int)grid.x == c->max_kp && c->qa == 5 * 64 && c->qu == 9 * 64 && c->qb == 2 * 64)
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false, 5, 9, 2>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
                            d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want);
