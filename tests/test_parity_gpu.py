@@ -455,3 +455,34 @@ def test_mirror_symmetry_of_detection_at_full_size(sift, flip):
         return out
     sa, sb = keyset(ka, na, False), keyset(kb, nb, True)
     assert sa == sb and len(sa) > 5000
+
+
+def test_large_batch_takes_grouped_slots(sift, orc):
+    """From ~33 frames per launch on the descriptor kernel gives every wave a group of slots (and the
+    batch heuristics of the other kernels change): 40 frames in one launch, each against the oracle,
+    and the same frames through the host-side stand-alone calls' kernels with 40 planes."""
+    import torch
+    W, H, B, K = 320, 240, 40, 10000
+    imgs = np.stack([orc.synth_frame(300 + s, W, H) for s in range(B)])
+    with sift.SiftContext(W, H, max_batch=B) as ctx:
+        d_img = torch.from_numpy(imgs).cuda()
+        d_kps = torch.full((B, K, 2), -1, dtype=torch.int32, device="cuda")
+        d_desc = torch.full((B, K, 72), -1, dtype=torch.int32, device="cuda")
+        d_tot = torch.zeros(B, dtype=torch.int32, device="cuda")
+        ctx.detect_and_compute_dev(d_img, B, d_kps, d_desc, d_tot)
+        d_grad = torch.zeros((B, H, W), dtype=torch.int32, device="cuda")
+        d_kps2 = torch.zeros_like(d_kps)
+        d_ori = torch.zeros((B, K), dtype=torch.uint8, device="cuda")
+        d_desc2 = torch.zeros_like(d_desc)
+        ctx.detect_dev(d_img, B, d_grad, d_kps2)
+        ctx.main_orientation_dev(d_grad, B, d_kps2, d_ori)
+        ctx.descriptor_dev(d_grad, B, d_kps2, d_ori, d_desc2)
+        ctx.sync()
+        assert torch.equal(d_kps, d_kps2) and torch.equal(d_desc, d_desc2)
+        kps = d_kps.cpu().numpy().view(sift.KP_DTYPE).reshape(B, K)
+        desc = d_desc.cpu().numpy().view(np.uint32)
+        for b in range(B):
+            rk, rd, total = orc.detect_and_compute(imgs[b])
+            n = nvalid(rk)
+            assert (kps[b] == rk).all() and (desc[b, :n] == rd[:n]).all() and not desc[b, n:].any(), b
+            assert int(d_tot[b].item()) == total
