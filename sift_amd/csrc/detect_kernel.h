@@ -194,21 +194,25 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
     cmap[lane + 64] = 0ull;
     __syncthreads();
     const bool colvalid = g < W4;
-    const uint32_t cmask = colvalid ? 0xffffffffu : 0u;
-    const uint32_t gc = colvalid ? (uint32_t)g : 0u;
     // halo column: the pixel left of the wave for lane 0, right of it for lane 63
     const int gh = lane == 0 ? g - 1 : g + 1;
-    const bool hvalid = gh >= 0 && gh < W4;
-    const uint32_t hmask = hvalid ? 0xffffffffu : 0u;
-    const uint32_t ghc = hvalid ? (uint32_t)gh : 0u;
     const int hp = lane == 0 ? 3 : 0;                 // its pixel inside that group
 
+    // A row is read through a buffer descriptor of exactly its W4 groups (none for rows outside the
+    // image): lanes beyond the row, the halo lanes at the frame's left and right edge (offset -16
+    // wraps to 4 GB) and rows above / below the image get zeros from the bounds check, which is what
+    // "outside the image reads 0" needs -- no masks, no address arithmetic in the loop.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t goff = (uint32_t)g * 16u, hoff = (uint32_t)gh * 16u;
     auto load_row = [&](int r, uint4 &Q, uint4 &Qh) {
-        const uint4 *rp = (r >= 0 && r < H) ? fp + (size_t)r * W4 : zero_row;   // wave-uniform
-        Q = rp[gc];
-        Qh = rp[ghc];
+        const bool in = r >= 0 && r < H;                                         // wave-uniform
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint4 *>(fp + (size_t)(in ? r : 0) * W4), 0, in ? W4 * 16 : 0, 0x00020000);
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)goff, 0, 0);
+        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)hoff, 0, 0);
+        Q = make_uint4(a.x, a.y, a.z, a.w);
+        Qh = make_uint4(b.x, b.y, b.z, b.w);
     };
-    auto masked = [](uint4 q, uint32_t m) { q.x &= m; q.y &= m; q.z &= m; q.w &= m; return q; };
 
     // Per column and row: e = max(D1, D3), f = min(D1, D3), b = D2.  Three rows are held (y-1, y,
     // y+1) in three slots whose roles rotate: the loop body exists once per rotation phase, so no
@@ -241,9 +245,9 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
     // prologue: rows ys-1 (slot 0) and ys (slot 1)
     uint4 Q, Qh, Qn, Qhn;
     load_row(ys - 1, Q, Qh);
-    push(masked(Q, cmask), masked(Qh, hmask), 0);
+    push(Q, Qh, 0);
     load_row(ys, Q, Qh);
-    push(masked(Q, cmask), masked(Qh, hmask), 1);
+    push(Q, Qh, 1);
     load_row(ys + 1, Qn, Qhn);
 
     uint2 gb0 = make_uint2(0u, 0u), gb1 = gb0, gb2 = gb0;   // gradient words of rows 4k .. 4k+2 until row 4k+3 is done
@@ -252,8 +256,9 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, co
     // one image row; A, B, C = slots of rows y-1, y, y+1 (C is overwritten with row y+1)
     auto row = [&](int y, auto ka, auto kb, auto kc) {
         constexpr int A = decltype(ka)::value, B = decltype(kb)::value, C = decltype(kc)::value;
-        Q = masked(Qn, cmask); Qh = masked(Qhn, hmask);                 // row y+1
-        load_row(y + 2, Qn, Qhn);                                        // prefetch (a row past the strip is harmless)
+        Q = Qn; Qh = Qhn;                                                // row y+1
+        load_row(y + 2, Qn, Qhn);                                        // prefetch (a row past the strip is harmless; requesting rows
+                                                                         // three iterations ahead was measured: 1.3 % slower)
         push(Q, Qh, C);
 
         // per column: max/min over the three rows
