@@ -31,8 +31,9 @@
 // No LDS, no barriers: neighbouring threads' loads overlap and are served by
 // the vector L1; the next input row is loaded one iteration ahead.  Out-of-image
 // taps read 0 (DetectKeypoints.cpp:968-991; the top rows, uninitialised in the
-// reference, are defined as 0): rows outside the image are read from a row of
-// zeros, columns outside are masked.
+// reference, are defined as 0): every row is read through a buffer descriptor of
+// exactly its W bytes (none for rows outside the image), so those taps are the
+// zeros of the hardware's bounds check.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -261,8 +262,8 @@ __device__ __forceinline__ uint32_t pack4_q15(const uint64_t (&a)[2])
 // "pyr" plane: one uint4 per group of 4 pixels = { src, G1, G2, G3 }, each a dword with pixel p
 // of the group in byte p.
 //
-// grid: x = ceil(W/4 / blockDim) blocks, y = strips, z = frames.  `zero_row` points at >= W bytes
-// of zeros: rows outside the image are read from there, so the row loads need no test.
+// grid: x = ceil(W/4 / blockDim) blocks, y = strips, z = frames.  `zero_row` is no longer read
+// (rows outside the image come from the buffer descriptors' bounds check).
 // GUARD: skip slot groups whose rows lie outside the strip (short strips: small batches).  Without
 // it every slot is updated in every iteration, through the symmetric scheme above (long strips).
 template <bool GUARD>
@@ -278,25 +279,21 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, 
     const uint32_t *__restrict__ img = reinterpret_cast<const uint32_t *>(imgs + fofs);
     uint4 *__restrict__ out = pyr + (fofs >> 2);
 
-    // column part of the 7 raw-dword addresses; columns outside the row are masked to 0
-    uint32_t qc[7], cm[7];
+    // A row is read through a buffer descriptor of exactly its W bytes (none for rows outside the
+    // image): the dwords left and right of the row (offsets below 0 wrap to 4 GB) and whole rows
+    // above / below the image come back as zeros from the bounds check -- no masks, no row of zeros,
+    // no address arithmetic in the loop.
+    uint32_t qoff[7];
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-        const int q = xq - 3 + k;
-        const bool v = (q >= 0) && (q < W4);
-        cm[k] = v ? 0xffffffffu : 0u;
-        qc[k] = (uint32_t)(v ? q : xq) * 4u;
-        // a real register: left to itself the compiler keeps the condition in an SGPR pair, runs out
-        // of SGPRs (the dot4 weights live there) and reloads the pairs with v_readlane in the loop
-        asm volatile("" : "+v"(cm[k]));
-    }
-    auto row_ptr = [&](int i) -> const char * {      // wave-uniform
-        return reinterpret_cast<const char *>((i >= 0 && i < H) ? img + (size_t)i * W4 : zero_row);
+    for (int k = 0; k < 7; k++) qoff[k] = (uint32_t)(xq - 3 + k) * 4u;
+    auto row_rsrc = [&](int i) {                     // wave-uniform
+        const bool in = i >= 0 && i < H;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(img + (size_t)(in ? i : 0) * W4), 0, in ? W : 0, 0x00020000);
     };
     auto load_row = [&](int i, uint32_t (&A)[7]) {
-        const char *rp = row_ptr(i);
+        const __amdgpu_buffer_rsrc_t rs = row_rsrc(i);
 #pragma unroll
-        for (int k = 0; k < 7; k++) A[k] = *reinterpret_cast<const uint32_t *>(rp + qc[k]);
+        for (int k = 0; k < 7; k++) A[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)qoff[k], 0, 0);
     };
 
     // per slot 4 x u32 (GUARD) or 2 x u64 (pixel pairs, see slide_sym)
@@ -317,17 +314,14 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, 
         for (int p = 0; p < NP; p++) a1[s][p] = 0;
     uint32_t d1[7] = {0, 0, 0, 0, 0, 0, 0}, d2[4] = {0, 0, 0, 0};
 
-    // c[]: the masked dwords of the current row; the next row is loaded one iteration ahead and
-    // masked into c[] at the bottom (the masking doubles as the hand-over: no register copies)
+    // c[]: the dwords of the current row; the next row is loaded one iteration ahead
     uint32_t c[7], nxt[7];
-    load_row(ys - 9, nxt);
-#pragma unroll
-    for (int k = 0; k < 7; k++) c[k] = nxt[k] & cm[k];
+    load_row(ys - 9, c);
     for (int i = ys - 9; i < ye + 9; ++i) {
         load_row(i + 1, nxt);                 // prefetch: consumed at the bottom
         // source dword of the row that finishes in this iteration (used at the bottom)
         const int y3 = i - 9;
-        const uint32_t sp = *reinterpret_cast<const uint32_t *>(row_ptr(y3) + qc[3]);
+        const uint32_t sp = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(row_rsrc(y3), (int)qoff[3], 0, 0);
         uint32_t w[4][5];
 #pragma unroll
         for (int j = 0; j < 5; j++) {
@@ -373,7 +367,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, 
         d2[0] = pack4_q15(a2[0]);
 
 #pragma unroll
-        for (int k = 0; k < 7; k++) c[k] = nxt[k] & cm[k];
+        for (int k = 0; k < 7; k++) c[k] = nxt[k];
     }
 }
 
