@@ -314,14 +314,14 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, 
         for (int p = 0; p < NP; p++) a1[s][p] = 0;
     uint32_t d1[7] = {0, 0, 0, 0, 0, 0, 0}, d2[4] = {0, 0, 0, 0};
 
-    // c[]: the dwords of the current row; the next row is loaded one iteration ahead
-    uint32_t c[7], nxt[7];
+    // c[]: the dwords of the current row; the next row is requested as soon as the windows are
+    // built from them (one iteration ahead) and lands in the same registers
+    uint32_t c[7];
     load_row(ys - 9, c);
+    // two rows per trip: half the copies of the delay lines and of the row hand-over (four rows
+    // need more than 256 VGPRs in the long-strip variant and were slower in the short-strip one)
+#pragma unroll 2
     for (int i = ys - 9; i < ye + 9; ++i) {
-        load_row(i + 1, nxt);                 // prefetch: consumed at the bottom
-        // source dword of the row that finishes in this iteration (used at the bottom)
-        const int y3 = i - 9;
-        const uint32_t sp = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(row_rsrc(y3), (int)qoff[3], 0, 0);
         uint32_t w[4][5];
 #pragma unroll
         for (int j = 0; j < 5; j++) {
@@ -330,6 +330,10 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, 
             w[2][j] = __builtin_amdgcn_alignbyte(c[j + 2], c[j + 1], 1);
             w[3][j] = __builtin_amdgcn_alignbyte(c[j + 2], c[j + 1], 2);
         }
+        load_row(i + 1, c);                   // prefetch: consumed in the next iteration
+        // source dword of the row that finishes in this iteration (used at the bottom)
+        const int y3 = i - 9;
+        const uint32_t sp = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(row_rsrc(y3), (int)qoff[3], 0, 0);
 
         if constexpr (GUARD) {
             // slot s of table n holds output row  i - off + s  (off = 9/5/2);
@@ -366,8 +370,6 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, 
         for (int k = 3; k > 0; k--) d2[k] = d2[k - 1];
         d2[0] = pack4_q15(a2[0]);
 
-#pragma unroll
-        for (int k = 0; k < 7; k++) c[k] = nxt[k];
     }
 }
 
