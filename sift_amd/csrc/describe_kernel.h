@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_grad_pairs(const uint4 *__restrict__ gr
 // NA, NU, NB > 0: the quad table has exactly NA, NU and NB steps of 64 quads (the reference's masks:
 // 5, 9 and 2) and the sweep is straight-line code with every load of the window in flight at once
 template <int GFMT, int MODE, bool LOOP = false, int NA = 0, int NU = 0, int NB = 0>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_describe(const void *__restrict__ gradv, const kp_t *__restrict__ kps,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_describe(const void *__restrict__ gradv, const kp_t *__restrict__ kps,
                                                  const uint8_t *__restrict__ ori_in, uint8_t *__restrict__ ori_out,
                                                  uint32_t *__restrict__ desc, const uint2 *__restrict__ tab,
                                                  int n2, int n2pad, int ntab, const void *__restrict__ qtab,
