@@ -262,13 +262,12 @@ __device__ __forceinline__ uint32_t pack4_q15(const uint64_t (&a)[2])
 // "pyr" plane: one uint4 per group of 4 pixels = { src, G1, G2, G3 }, each a dword with pixel p
 // of the group in byte p.
 //
-// grid: x = ceil(W/4 / blockDim) blocks, y = strips, z = frames.  `zero_row` is no longer read
-// (rows outside the image come from the buffer descriptors' bounds check).
+// grid: x = ceil(W/4 / blockDim) blocks, y = strips, z = frames.
 // GUARD: skip slot groups whose rows lie outside the strip (short strips: small batches).  Without
 // it every slot is updated in every iteration, through the symmetric scheme above (long strips).
 template <bool GUARD>
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, uint4 *__restrict__ pyr,
-                                              const uint32_t *__restrict__ zero_row, int W, int H, int rows)
+                                              int W, int H, int rows)
 {
     const int W4 = W >> 2;
     const int xq = blockIdx.x * blockDim.x + threadIdx.x;

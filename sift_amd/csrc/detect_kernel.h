@@ -171,7 +171,7 @@ constexpr int DETECT_QUEUE = 256 * DETECT_ROWS / 4;   // strict extrema are neve
 
 // grid: x = ceil(W/256) spans, y = strips of `rows` <= DETECT_ROWS, z = frames; block = 64 (one wave)
 template <bool FULLGRAD>
-__global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr, const uint4 *__restrict__ zero_row,
+__global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
                                                u64 *__restrict__ candmask, uint32_t *__restrict__ keyplane,
                                                u64 *__restrict__ survmask, uint32_t *__restrict__ rowcount,
                                                uint32_t *__restrict__ list, uint32_t *__restrict__ listcount,

@@ -209,7 +209,6 @@ struct sift_hip_ctx {
     // persistent scratch, max_batch frames each
     uint8_t *d_img = nullptr;             // staging for host-buffer entry points
     uint4 *d_pyr = nullptr;               // {src, G1, G2, G3} dwords per group of 4 pixels
-    uint4 *d_zero = nullptr;              // a row of zeros (4*W bytes): rows outside the image
     unsigned long long *d_cand = nullptr, *d_surv = nullptr;   // [H][S] bit masks
     uint32_t *d_list = nullptr, *d_listcount = nullptr;        // k_detect's candidate list per frame
     int list_cap = 0;
@@ -320,11 +319,9 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
         // long strips: the 18 warm-up rows are a small share, every slot is updated in every
         // iteration with the symmetric scheme; short strips skip the slots outside the strip
         if (rows >= c->blur_sym_rows)
-            hipLaunchKernelGGL(sift::k_blur<false>, grid, dim3(bs), 0, s, d_imgs, c->d_pyr,
-                               reinterpret_cast<const uint32_t *>(c->d_zero), W, H, rows);
+            hipLaunchKernelGGL(sift::k_blur<false>, grid, dim3(bs), 0, s, d_imgs, c->d_pyr, W, H, rows);
         else
-            hipLaunchKernelGGL(sift::k_blur<true>, grid, dim3(bs), 0, s, d_imgs, c->d_pyr,
-                               reinterpret_cast<const uint32_t *>(c->d_zero), W, H, rows);
+            hipLaunchKernelGGL(sift::k_blur<true>, grid, dim3(bs), 0, s, d_imgs, c->d_pyr, W, H, rows);
     }
     {
         StageTimer t(c, ST_DETECT, s);
@@ -339,11 +336,11 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
         drows = std::max(4, std::min(drows, (int)sift::DETECT_ROWS));
         dim3 grid(spans, (H + drows - 1) / drows, nframes);
         if (d_gradfull)
-            hipLaunchKernelGGL(sift::k_detect<true>, grid, dim3(64), 0, s, c->d_pyr, c->d_zero, c->d_cand, c->d_key,
+            hipLaunchKernelGGL(sift::k_detect<true>, grid, dim3(64), 0, s, c->d_pyr, c->d_cand, c->d_key,
                                c->d_surv, c->d_rowcount, c->d_list, c->d_listcount, c->d_gradp, d_gradfull, W, H, S,
                                th, c->list_cap, drows);
         else
-            hipLaunchKernelGGL(sift::k_detect<false>, grid, dim3(64), 0, s, c->d_pyr, c->d_zero, c->d_cand, c->d_key,
+            hipLaunchKernelGGL(sift::k_detect<false>, grid, dim3(64), 0, s, c->d_pyr, c->d_cand, c->d_key,
                                c->d_surv, c->d_rowcount, c->d_list, c->d_listcount, c->d_gradp,
                                (uint32_t *)nullptr, W, H, S, th, c->list_cap, drows);
     }
@@ -500,8 +497,6 @@ int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int m
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     A((void **)&c->d_img, B * np);
     A((void **)&c->d_pyr, B * np * 4);
-    A((void **)&c->d_zero, (size_t)width * 4 + 64);
-    if (e == hipSuccess) e = hipMemset(c->d_zero, 0, (size_t)width * 4 + 64);
     c->list_cap = (int)std::min<size_t>(np / 2 + 64, 0x7fffffff);
     A((void **)&c->d_list, B * (size_t)c->list_cap * 4);
     A((void **)&c->d_listcount, B * 4);
@@ -536,7 +531,7 @@ void sift_hip_destroy(sift_hip_ctx *c)
     if (!c) return;
     DevGuard g(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->d_img, c->d_pyr, c->d_zero, c->d_list, c->d_listcount, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_gradp,
+    void *ptrs[] = {c->d_img, c->d_pyr, c->d_list, c->d_listcount, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_gradp,
                     c->d_gradfull, c->d_final, c->d_findex, c->d_nvalid, c->d_tfinal, c->d_tindex, c->d_tdesc, c->d_tnvalid, c->d_bgr, c->d_kps, c->d_desc, c->d_total, c->d_total_ctx, c->d_ori, c->d_tab, c->d_qtab, c->d_gate};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &ps : c->prof)
