@@ -147,8 +147,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     // slots blockIdx.x, + gridDim.x, ...; in the fused mode `total` (k_emit's count) tells which
     // slots are padding without reading them
     const int nfilled = total ? (int)min(total[blockIdx.y], (uint32_t)max_kp) : max_kp;
-    // LOOP = false: the grid has one workgroup per slot
-    for (int kslot = blockIdx.x; kslot < max_kp; kslot += LOOP ? (int)gridDim.x : max_kp) {
+    // LOOP = false: the grid has one workgroup per slot.  LOOP = true (gridDim.x a multiple of 8):
+    // workgroups are dealt round-robin over the 8 XCDs, so workgroup x runs on XCD x & 7; XCD k takes
+    // the k-th eighth of the filled slots -- a band of the raster-ordered keypoints, so that its L2
+    // holds one band of the gradient plane instead of all of it -- and then the k-th eighth of the
+    // padding slots; the workgroups of an XCD stride through its list.
+    const int bs = (nfilled + 7) >> 3, pb = (max_kp - nfilled + 7) >> 3;
+    for (int v = blockIdx.x; v < (LOOP ? 8 * (bs + pb) : max_kp); v += LOOP ? (int)gridDim.x : max_kp) {
+    int kslot = v;
+    if constexpr (LOOP) {
+        const int xcd = v & 7;
+        int r = v >> 3;
+        if (r < bs) {
+            kslot = xcd * bs + r;
+            if (kslot >= nfilled) continue;
+        } else {
+            r -= bs;
+            kslot = nfilled + xcd * pb + r;
+            if (r >= pb || kslot >= max_kp) continue;
+        }
+    }
     const size_t slot = (size_t)blockIdx.y * max_kp + kslot;
     if (kslot >= nfilled) {                          // padding slot: descriptor defined as 0
         desc[slot * 72 + lane] = 0;

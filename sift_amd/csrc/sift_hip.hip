@@ -373,7 +373,7 @@ int run_describe(sift_hip_ctx *c, const void *d_grad, int nframes, const sift::k
     // nothing: measured 0.684 against 0.691 ms per 64 frames with two slots per wave)
     const bool fused = MODE == sift::DESC_FUSED;
     const int gx = std::max(1024, std::min(c->max_kp, (327680 + nframes - 1) / nframes));
-    dim3 grid(std::min(gx, c->max_kp), nframes);
+    dim3 grid(gx >= c->max_kp ? c->max_kp : (gx & ~7), nframes);   // grouped slots: a multiple of 8 (one share per XCD)
     const uint32_t *tot = fused ? (const uint32_t *)c->d_total_ctx : (const uint32_t *)nullptr;
     // the reference's masks give 5 + 9 + 2 steps of 64 quads: straight-line variant
     if (GFMT == sift::GRAD_PACKED16 && (int)grid.x == c->max_kp && c->qa == 5 * 64 && c->qu == 9 * 64 && c->qb == 2 * 64)
