@@ -166,7 +166,13 @@ __device__ __forceinline__ int edge_at(const uint4 *__restrict__ fp, int W4, int
 }
 
 constexpr int DETECT_ROWS = 32;                       // most rows per strip (LDS is sized for it)
-constexpr int DETECT_QUEUE = 256 * DETECT_ROWS / 4;   // strict extrema are never 8-adjacent
+// LDS queue of the pixels that passed the extremum and contrast tests.  A row adds at most 256
+// entries (4 pixels x 64 lanes); when the next three rows might not fit the queue is drained (edge
+// test, survivors appended to the frame's list) in the middle of the strip, so no density of
+// extrema can overflow it.  (A strict maximum and a strict minimum may be neighbours, so
+// "never 8-adjacent" bounds only each kind by 1/4; real frames stay near 1 %.)
+constexpr int DETECT_QUEUE = 256 * DETECT_ROWS / 4;
+static_assert(DETECT_QUEUE >= 3 * 256, "three rows must fit after a drain");
 
 
 // grid: x = ceil(W/256) spans, y = strips of `rows` <= DETECT_ROWS, z = frames; block = 64 (one wave)
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
                                                u64 *__restrict__ survmask, uint32_t *__restrict__ rowcount,
                                                uint32_t *__restrict__ list, uint32_t *__restrict__ listcount,
                                                uint16_t *__restrict__ gradp, uint32_t *__restrict__ gradfull,
-                                               int W, int H, int S, int contrastTh, int list_cap, int rows)
+                                               int W, int H, int S, int contrastTh, int list_cap, int rows, int qcap)
 {
     __shared__ uint32_t queue[DETECT_QUEUE];
     __shared__ u64 cmap[DETECT_ROWS * 4];             // candidate bits of the strip: row-major, 4 words per row
@@ -252,6 +258,41 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
 
     uint2 gb0 = make_uint2(0u, 0u), gb1 = gb0, gb2 = gb0;   // gradient words of rows 4k .. 4k+2 until row 4k+3 is done
     uint32_t qcount = 0;                              // wave-uniform
+    const size_t frow = (size_t)frame * H;
+    // Edge test on the queue, one lane per entry; what passes is a pre-cull candidate: its key and
+    // its bit in cmap are written, and the entries are compacted in place and appended to the frame's
+    // list.  Runs at the end of the strip and whenever the queue is nearly full after a row.
+    auto drain = [&]() {
+        __syncthreads();
+        uint32_t ccount = 0;                          // wave-uniform
+        for (uint32_t i0 = 0; i0 < qcount; i0 += 64) {
+            const bool live = i0 + lane < qcount;
+            const uint32_t e = live ? queue[i0 + lane] : 0u;
+            const int y = (int)(e >> 16), x = (int)(e & 0xffffu);
+            int ac;
+            const int ec = edge_at(fp, W4, W, H, y, x, &ac);
+            const bool cand = live && ec >= 0;                           // :200
+            if (cand) {
+                keyplane[fpix + (size_t)y * W + x] = ((uint32_t)ec << 8) | (uint32_t)ac;
+                atomicOr(&cmap[(y - ys) * 4 + ((x >> 6) & 3)], 1ull << (x & 63));
+            }
+            const u64 bal = __ballot(cand);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (cand) queue[ccount + below] = e;      // ccount + below <= i0 + lane: nothing unread is overwritten
+            ccount += (uint32_t)__popcll(bal);
+        }
+        __syncthreads();
+        if (ccount) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(listcount + frame, ccount);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            uint32_t *__restrict__ fl = list + (size_t)frame * list_cap;
+            for (uint32_t i = lane; i < ccount; i += 64)
+                if (base + i < (uint32_t)list_cap) fl[base + i] = queue[i];
+        }
+        __syncthreads();
+        qcount = 0;
+    };
     const int th1 = max(contrastTh, 1);               // |D2| >= contrastTh (:194) and |D2| != 0 (:684) in one test
     // one image row; A, B, C = slots of rows y-1, y, y+1 (C is overwritten with row y+1)
     auto row = [&](int y, auto ka, auto kb, auto kc) {
@@ -359,34 +400,17 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
         using K0 = std::integral_constant<int, 0>;
         using K1 = std::integral_constant<int, 1>;
         using K2 = std::integral_constant<int, 2>;
+        // after three rows at most 3 x 256 new entries: drain while that many may not fit (qcap is
+        // DETECT_QUEUE except in the test that forces drains, sift_hip_set_detect_queue)
         for (int y = ys; y < ye; y += 3) {
             row(y, K0{}, K1{}, K2{});
             if (y + 1 < ye) row(y + 1, K1{}, K2{}, K0{});
             if (y + 2 < ye) row(y + 2, K2{}, K0{}, K1{});
+            if (qcount + 3u * 256u > (uint32_t)qcap) drain();
         }
     }
 
-    // edge test on the queue, one lane per entry; survivors of it are compacted in place
-    __syncthreads();
-    const size_t frow = (size_t)frame * H;
-    uint32_t ccount = 0;                              // wave-uniform
-    for (uint32_t i0 = 0; i0 < qcount; i0 += 64) {
-        const bool live = i0 + lane < qcount;
-        const uint32_t e = live ? queue[i0 + lane] : 0u;
-        const int y = (int)(e >> 16), x = (int)(e & 0xffffu);
-        int ac;
-        const int ec = edge_at(fp, W4, W, H, y, x, &ac);
-        const bool cand = live && ec >= 0;                           // :200
-        if (cand) {
-            keyplane[fpix + (size_t)y * W + x] = ((uint32_t)ec << 8) | (uint32_t)ac;
-            atomicOr(&cmap[(y - ys) * 4 + ((x >> 6) & 3)], 1ull << (x & 63));
-        }
-        const u64 bal = __ballot(cand);
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (cand) queue[ccount + below] = e;          // ccount + below <= i0 + lane: nothing unread is overwritten
-        ccount += (uint32_t)__popcll(bal);
-    }
-    __syncthreads();
+    drain();
     // every mask word of the strip: candidates as found, survivors empty (k_cull sets them)
 #pragma unroll
     for (int k = 0; k < 2; k++) {
@@ -397,14 +421,6 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
         }
     }
     if (blockIdx.x == 0 && lane < ye - ys) rowcount[frow + ys + lane] = 0u;
-    if (ccount) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(listcount + frame, ccount);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        uint32_t *__restrict__ fl = list + (size_t)frame * list_cap;
-        for (uint32_t i = lane; i < ccount; i += 64)
-            if (base + i < (uint32_t)list_cap) fl[base + i] = queue[i];
-    }
 }
 
 }  // namespace sift

@@ -240,6 +240,7 @@ struct sift_hip_ctx {
     int gseen = 0;                        // consecutive calls of the shape in gkey
     int graph_max_frames = 4;             // calls with more frames are launched kernel by kernel (0: never use a graph)
     int detect_rows = 0;                  // rows per k_detect strip (0 = heuristic)
+    int detect_queue = sift::DETECT_QUEUE; // LDS queue entries k_detect uses before it drains (test knob)
     int blur_sym_rows = 48;               // strips at least this long run k_blur<false>
     // profiling: a ring of `nslots` calls, one HIP event pair per kernel of a call
     struct ProfSlot { hipEvent_t ev[SIFT_HIP_NSTAGES][2] = {}; bool used[SIFT_HIP_NSTAGES] = {}; };
@@ -338,11 +339,11 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
         if (d_gradfull)
             hipLaunchKernelGGL(sift::k_detect<true>, grid, dim3(64), 0, s, c->d_pyr, c->d_cand, c->d_key,
                                c->d_surv, c->d_rowcount, c->d_list, c->d_listcount, c->d_gradp, d_gradfull, W, H, S,
-                               th, c->list_cap, drows);
+                               th, c->list_cap, drows, c->detect_queue);
         else
             hipLaunchKernelGGL(sift::k_detect<false>, grid, dim3(64), 0, s, c->d_pyr, c->d_cand, c->d_key,
                                c->d_surv, c->d_rowcount, c->d_list, c->d_listcount, c->d_gradp,
-                               (uint32_t *)nullptr, W, H, S, th, c->list_cap, drows);
+                               (uint32_t *)nullptr, W, H, S, th, c->list_cap, drows, c->detect_queue);
     }
     {
         StageTimer t(c, ST_CULL, s);
@@ -513,7 +514,6 @@ int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int m
     A((void **)&c->d_tab, tab.size() * sizeof(uint2));
     c->ntab = (int)tab.size(); c->n2 = wt.n2; c->n2pad = wt.n2pad;
     c->qa = qt.qa; c->qu = qt.qu; c->qb = qt.qb;
-    if (const char *v = getenv("SIFT_HIP_GRAPH_FRAMES")) c->graph_max_frames = std::max(0, atoi(v));   // tuning knob
     A((void **)&c->d_gate, 4);
     A((void **)&c->d_qtab, qt.bytes.size());
     if (e == hipSuccess) e = hipMemcpy(c->d_qtab, qt.bytes.data(), qt.bytes.size(), hipMemcpyHostToDevice);
@@ -600,6 +600,17 @@ int sift_hip_set_detect_rows(sift_hip_ctx *c, int rows)
     if (int r = check_ctx(c)) return r;
     if (rows < 0) return fail(SIFT_HIP_EINVAL, "rows must be >= 0");
     c->detect_rows = rows;
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_set_detect_queue(sift_hip_ctx *c, int entries)
+{
+    if (int r = check_ctx(c)) return r;
+    if (entries < 0) return fail(SIFT_HIP_EINVAL, "entries must be >= 0");
+    c->detect_queue = entries == 0 ? (int)sift::DETECT_QUEUE : std::max(3 * 256, std::min(entries, (int)sift::DETECT_QUEUE));
+    if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }   // a captured graph holds the old value
+    c->gkey = sift_hip_ctx::GraphKey{};
+    c->gseen = 0;
     return SIFT_HIP_OK;
 }
 

@@ -183,6 +183,10 @@ class SiftContext:
     def set_detect_rows(self, rows):
         check(self._lib.sift_hip_set_detect_rows(self._h, int(rows)))
 
+    def set_detect_queue(self, entries):
+        """test knob: LDS queue entries k_detect fills before draining mid-strip (0 = default)"""
+        check(self._lib.sift_hip_set_detect_queue(self._h, int(entries)))
+
     def stage_ms(self, back=0):
         """kernel times (ms) of the call `back` calls before the most recent one"""
         ms = (C.c_float * NSTAGES)()

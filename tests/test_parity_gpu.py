@@ -486,3 +486,68 @@ def test_large_batch_takes_grouped_slots(sift, orc):
             n = nvalid(rk)
             assert (kps[b] == rk).all() and (desc[b, :n] == rd[:n]).all() and not desc[b, n:].any(), b
             assert int(d_tot[b].item()) == total
+
+
+def _oracle_frames(orc, imgs, th=15):
+    """the oracle on every frame, frame-parallel (ctypes releases the GIL inside the C call)"""
+    from concurrent.futures import ThreadPoolExecutor
+    workers = max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", "8")), os.cpu_count() or 1))
+    with ThreadPoolExecutor(workers) as ex:
+        return list(ex.map(lambda im: orc.detect_and_compute(im, th), imgs))
+
+
+def test_bench_shape_against_the_oracle(sift, orc):
+    """cfg 4 at full size, the shape bench.py runs: 1920x1080 frames, more than 33 of them in one
+    sift_hip_detect_and_compute_dev call, ~9,500 keypoints each -- so the grouped-slot descriptor
+    kernel with one band of keypoints per XCD (k_describe<..., LOOP = true, 5, 9, 2>) and the
+    long-strip blur kernel (k_blur<false>) run as they do in the bench.  Every frame's keypoint array,
+    valid descriptors, zero padding and total against the oracle (HW_SIFT.cpp:29-41 per frame)."""
+    import torch
+    W, H, B, K = 1920, 1080, 36, 10000
+    imgs = np.stack([orc.synth_frame(1 + s, W, H) for s in range(B)])
+    ref = _oracle_frames(orc, imgs)
+    with sift.SiftContext(W, H, max_batch=B) as ctx:
+        d_img = torch.from_numpy(imgs).cuda()
+        d_kps = torch.full((B, K, 2), -1, dtype=torch.int32, device="cuda")
+        d_desc = torch.full((B, K, 72), -1, dtype=torch.int32, device="cuda")
+        d_tot = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+        ctx.detect_and_compute_dev(d_img, B, d_kps, d_desc, d_tot)
+        ctx.sync()
+        kps = d_kps.cpu().numpy().view(sift.KP_DTYPE).reshape(B, K)
+        desc = d_desc.cpu().numpy().view(np.uint32)
+        tot = d_tot.cpu().numpy()
+    nsum = 0
+    for b in range(B):
+        rk, rd, total = ref[b]
+        n = nvalid(rk)
+        nsum += n
+        assert (kps[b] == rk).all(), "keypoints of frame %d" % b
+        assert (desc[b, :n] == rd[:n]).all(), "descriptors of frame %d" % b
+        assert not desc[b, n:].any() and int(tot[b]) == total, b
+    assert nsum > 9000 * B                                          # dense frames, as in the bench
+
+
+def test_detect_queue_drains_in_mid_strip(sift, orc):
+    """k_detect queues the pixels that pass the extremum and contrast tests in LDS and drains the
+    queue when the next rows might not fit (a strict maximum and a strict minimum may be neighbours,
+    so no density bound protects a fixed-size queue).  Noise at contrastTh = 0 with the smallest
+    queue forces a drain after almost every group of rows; every stage must still match the oracle."""
+    rng = np.random.default_rng(17)
+    H, W = 300, 520
+    noise = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    coarse = np.repeat(np.repeat(rng.integers(0, 256, (H // 2, W // 2), dtype=np.uint8), 2, 0), 2, 1)
+    for img in (noise, coarse):
+        for th in (0, 3):
+            rk, rd, total = orc.detect_and_compute(img, th)
+            ref = orc.sift_detect(img, th, planes=True)
+            n = nvalid(rk)
+            with sift.SiftContext(W, H) as ctx:
+                for q in (768, 1000, 0):
+                    ctx.set_detect_queue(q)
+                    kps, desc = ctx.sift_detect_and_compute(img, th)
+                    assert (kps == rk).all() and (desc[:n] == rd[:n]).all() and not desc[n:].any(), (th, q)
+                    pl = ctx.debug_planes(0)
+                    assert (pl["cand"] == ref["kp1"]).all() and (pl["surv"] == ref["kp2"]).all(), (th, q)
+                    m = ref["kp1"] > 0
+                    assert (pl["eratio"][m] == ref["eratio"][m]).all()
+            assert int((ref["kp1"] > 0).sum()) > 100                # with the smallest queue every group of rows that queued anything drains
