@@ -172,6 +172,30 @@ int sift_hip_select_top_dev(sift_hip_ctx *ctx, const sift_keypoint *d_kps, int n
 int sift_hip_gray_from_bgr_dev(sift_hip_ctx *ctx, const uint8_t *d_bgr, int nframes, long pitch, int bottom_up,
                                uint8_t *d_gray, void *stream);
 
+/* sift_hip_detect_and_compute_dev for callers that cannot allocate: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE
+ * (its sift_detect_and_compute allocates scratch on every call, HW_SIFT.cpp:23-24).  It takes no
+ * context: all device scratch lives in one static __device__ array of
+ * SIFT_HIP_STATIC_SCRATCH_BYTES inside the library (each GPU the process touches holds its own
+ * copy until the process ends), and the call makes no hipMalloc / hipFree and creates no stream,
+ * event or graph.  d_imgs, d_kps (nframes*10000 slots), d_desc (nframes*10000*72) and the optional
+ * d_total (nframes) are the caller's device buffers on `device`; max_keypoints is fixed at
+ * SIFT_HIP_MAX_KEYPOINTS; the work is enqueued on `stream` (NULL = the legacy default stream) and
+ * not waited for.
+ * Limit: sift_hip_static_scratch_needed(width, height, nframes) (about 12.3 bytes per pixel and
+ * frame + 0.26 MB) must not exceed SIFT_HIP_STATIC_SCRATCH_BYTES -- one 1920x1080 frame or six
+ * 640x480 frames fit; larger calls fail with SIFT_HIP_EINVAL and a message that says so.
+ * The first call on a device, and the first after the width changed, rebuilds the descriptor tables on
+ * the host, copies them on `stream` and waits for that copy: make that call outside stream capture.
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two
+ * threads) race; order them on one stream or with events. */
+#define SIFT_HIP_STATIC_SCRATCH_BYTES (32u << 20)
+int sift_hip_detect_and_compute_static(int device, const uint8_t *d_imgs, int nframes, int width, int height,
+                                       sift_keypoint *d_kps, uint32_t *d_desc, uint32_t *d_total, int contrastTh,
+                                       void *stream);
+/* Bytes of the static array a call of that shape uses (0 for an invalid shape). */
+unsigned long sift_hip_static_scratch_needed(int width, int height, int nframes);
+
 /* Block until everything this context enqueued has finished. */
 int sift_hip_sync(sift_hip_ctx *ctx);
 

@@ -14,6 +14,7 @@
 #include <optional>
 #include <vector>
 #include <thread>
+#include <mutex>
 #include <algorithm>
 #include <cmath>
 
@@ -1023,6 +1024,140 @@ int sift_hip_batch_top(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const
     if (nfinal < 1) return fail(SIFT_HIP_EINVAL, "nfinal must be >= 1");
     return batch_impl(ctxs, nctx, imgs, nframes, nullptr, nullptr, contrastTh, nfinal, final_kps, final_index, final_desc,
                       nvalid);
+}
+
+/* ---- the entry point that allocates nothing ------------------------------------------------ */
+}  // extern "C"
+
+// Scratch of sift_hip_detect_and_compute_static: every GPU the library runs on holds its own copy
+// of this array until the process ends.  In host code the name is only a stand-in for the symbol:
+// the address kernels and hipMemsetAsync get is the one hipGetSymbolAddress returns per device.
+static __device__ __align__(256) unsigned char scratch[SIFT_HIP_STATIC_SCRATCH_BYTES];
+
+namespace {
+
+constexpr int STATIC_MAX_DEVICES = 64;
+constexpr size_t STATIC_TABLE_BYTES = 256u << 10;     // front of the array: window + quad tables of the current width
+
+struct StaticState {
+    unsigned char *base = nullptr;        // this device's address of `scratch` (hipGetSymbolAddress)
+    int table_width = 0;                  // frame width the tables in the array were built for
+    sift_hip_ctx ctx;                     // views into the array; owns nothing
+};
+StaticState g_static[STATIC_MAX_DEVICES];
+std::mutex g_static_mu;
+
+// the buffers of a call, carved out of the array behind the tables (256-byte aligned)
+struct StaticLayout {
+    size_t pyr, list, listcount, cand, surv, key, rowcount, gradp, total, end;
+    StaticLayout(int W, int H, int nframes)
+    {
+        const size_t B = (size_t)nframes, np = (size_t)W * H, HS = (size_t)H * (size_t)((W + 63) / 64);
+        size_t o = STATIC_TABLE_BYTES;
+        auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+        pyr = take(B * np * 4);
+        list = take(B * (np / 2 + 64) * 4);
+        listcount = take(B * 4);
+        cand = take(B * HS * 8);
+        surv = take(B * HS * 8);
+        key = take(B * np * 4);
+        rowcount = take(B * (size_t)H * 4);
+        gradp = take(B * sift::gradp_frame_words(W, H) * 2);
+        total = take(B * 4);
+        end = o;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+unsigned long sift_hip_static_scratch_needed(int width, int height, int nframes)
+{
+    if (width < 4 || (width & 3) || height < 1 || width > 65532 || height > 65535 || nframes < 1) return 0;
+    return (unsigned long)StaticLayout(width, height, nframes).end;
+}
+
+int sift_hip_detect_and_compute_static(int device, const uint8_t *d_imgs, int nframes, int width, int height,
+                                       sift_keypoint *d_kps, uint32_t *d_desc, uint32_t *d_total, int contrastTh,
+                                       void *stream)
+{
+    if (!d_imgs || !d_kps || !d_desc) return fail(SIFT_HIP_EINVAL, "null buffer");
+    if (width < 4 || (width & 3) || height < 1 || width > 65532 || height > 65535)
+        return fail(SIFT_HIP_EINVAL, "width must be a multiple of 4 in [4,65532], height in [1,65535]");
+    if (nframes < 1) return fail(SIFT_HIP_EINVAL, "nframes must be >= 1");
+    if (device < 0 || device >= STATIC_MAX_DEVICES) return fail(SIFT_HIP_EINVAL, "device index out of range");
+    const StaticLayout L(width, height, nframes);
+    if (L.end > (size_t)SIFT_HIP_STATIC_SCRATCH_BYTES) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "%d frame(s) of %dx%d need %zu bytes of scratch, the static array holds %zu "
+                 "(use a context: sift_hip_create)", nframes, width, height, L.end, (size_t)SIFT_HIP_STATIC_SCRATCH_BYTES);
+        return fail(SIFT_HIP_EINVAL, buf);
+    }
+    std::lock_guard<std::mutex> lock(g_static_mu);
+    DevGuard g(device);
+    hipStream_t s = (hipStream_t)stream;
+    StaticState &st = g_static[device];
+    if (!st.base) {
+        // once per device, with that device current: its own address of the array
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SIFT_HIP_ENODEV, "no HIP device");
+        if (device >= ndev) return fail(SIFT_HIP_EINVAL, "device index out of range");
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(SIFT_HIP_ENODEV, "device is not gfx950 (the library carries gfx950 code only)");
+        unsigned char *p = nullptr;
+        HIP_TRY(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(SIFT_HIP_EHIP, "hipGetSymbolAddress gave no address");
+        st.base = p;
+        st.ctx.device = device;
+        st.ctx.max_kp = SIFT_HIP_MAX_KEYPOINTS;
+        st.ctx.graph_max_frames = 0;
+    }
+    sift_hip_ctx *c = &st.ctx;
+    if (st.table_width != width) {
+        // set-up for a new frame width (first call, or the width changed): the descriptor tables hold
+        // plane offsets, so they are rebuilt on the host and copied to the front of the array.  The
+        // copy is ordered on `stream` after whatever earlier call still reads the old tables, and the
+        // host waits for it (the vectors go away); this step cannot run under stream capture.
+        const WindowTable wt = build_window_table(width);
+        const QuadTable qt = build_quad_table(width);
+        if (wt.e.empty()) return fail(SIFT_HIP_EINVAL, "circle tables overlap three-fold");
+        if (2L * std::max(wt.kmax, qt.kmax) * sift::DESC_MAX_MAG_PACKED >= 65536)
+            return fail(SIFT_HIP_EINVAL, "descriptor window too large for 16-bit lane bins");
+        const size_t tab_bytes = wt.e.size() * sizeof(uint2), qoff = (tab_bytes + 255) & ~(size_t)255;
+        if (qoff + qt.bytes.size() > STATIC_TABLE_BYTES) return fail(SIFT_HIP_EINVAL, "descriptor tables exceed their share of the static array");
+        st.table_width = 0;
+        HIP_TRY(hipMemcpyAsync(st.base, wt.e.data(), tab_bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(st.base + qoff, qt.bytes.data(), qt.bytes.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        c->d_tab = (uint2 *)st.base;
+        c->d_qtab = (uint32_t *)(st.base + qoff);
+        c->ntab = (int)wt.e.size(); c->n2 = wt.n2; c->n2pad = wt.n2pad;
+        c->qa = qt.qa; c->qu = qt.qu; c->qb = qt.qb;
+        st.table_width = width;
+    }
+    c->W = width; c->H = height; c->S = (width + 63) / 64;
+    c->npix = (size_t)width * height;
+    c->max_batch = nframes;
+    c->list_cap = (int)std::min<size_t>(c->npix / 2 + 64, 0x7fffffff);
+    c->d_pyr = (uint4 *)(st.base + L.pyr);
+    c->d_list = (uint32_t *)(st.base + L.list);
+    c->d_listcount = (uint32_t *)(st.base + L.listcount);
+    c->d_cand = (unsigned long long *)(st.base + L.cand);
+    c->d_surv = (unsigned long long *)(st.base + L.surv);
+    c->d_key = (uint32_t *)(st.base + L.key);
+    c->d_rowcount = (uint32_t *)(st.base + L.rowcount);
+    c->d_gradp = (uint16_t *)(st.base + L.gradp);
+    c->d_total_ctx = (uint32_t *)(st.base + L.total);
+    c->cur = -1;                                      // no profiling records: they would need events
+    // The array keeps the previous call's contents.  What must start at zero is cleared by the
+    // kernels themselves, as for a context's scratch: the list counts by run_detect's memset, the
+    // survivor masks and row counts by k_detect; everything else is written before it is read.
+    if (int r = run_detect(c, d_imgs, nframes, nullptr, (sift::kp_t *)d_kps, d_total, contrastTh, s)) return r;
+    return run_describe<sift::GRAD_PACKED16, sift::DESC_FUSED>(c, c->d_gradp, nframes, (const sift::kp_t *)d_kps, nullptr,
+                                                               nullptr, d_desc, s);
 }
 
 int sift_hip_debug_planes(sift_hip_ctx *c, int frame, uint8_t *g1, uint8_t *g2, uint8_t *g3, uint16_t *cand,
