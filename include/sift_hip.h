@@ -226,6 +226,9 @@ const char *sift_hip_stage_name(int stage);
 
 /* Tuning knob: rows per thread strip of the blur kernel (0 = heuristic). */
 int sift_hip_set_blur_rows(sift_hip_ctx *ctx, int rows);
+/* Test / comparison knob: on = 0 runs the blurs on the vector ALUs (v_dot4_u32_u8, k_blur) instead of
+ * the matrix cores (v_mfma_i32_16x16x64_i8, k_blur_mfma).  Same bits either way.  Default: on. */
+int sift_hip_set_blur_mfma(sift_hip_ctx *ctx, int on);
 /* Tuning knob: sift_hip_detect_and_compute_dev calls of up to `max_frames` frames (default 4) that
  * repeat the previous call's buffers and parameters are replayed as one HIP graph; 0 = never. */
 int sift_hip_set_graph_frames(sift_hip_ctx *ctx, int max_frames);

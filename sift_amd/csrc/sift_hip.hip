@@ -20,6 +20,7 @@
 
 #include "../../include/sift_hip.h"
 #include "blur_kernel.h"
+#include "blur_mfma_kernel.h"
 #include "detect_kernel.h"
 #include "compact_kernel.h"
 #include "describe_kernel.h"
@@ -235,6 +236,7 @@ struct sift_hip_ctx {
     int ntab = 0, n2 = 0, n2pad = 0, qa = 0, qu = 0, qb = 0;
     bool quad_sweep = true;               // false: every window through the pixel sweep (sift_hip_set_quad_sweep)
     int blur_rows = 0;
+    bool blur_mfma = true;                // k_blur_mfma (matrix cores) instead of k_blur (dot4 VALU); sift_hip_set_blur_mfma
     // graph of the last fused call (small batches: launch gaps are a third of a single frame's time)
     struct GraphKey { const void *imgs = nullptr, *kps = nullptr, *desc = nullptr, *total = nullptr; int nframes = 0, th = 0, brows = 0, drows = 0; } gkey;
     hipGraphExec_t gexec = nullptr;
@@ -305,6 +307,27 @@ int pick_blur_rows(const sift_hip_ctx *c, int nframes)
     return best_rows;
 }
 
+// Strip length of k_blur_mfma: a wave takes 16 (strip, 16-pixel block) units and runs rows + 18
+// iterations; the chip holds 1024 waves (one per SIMD).  Few strips keep the 18 warm-up rows small,
+// many fill the chip when the batch is small: the cheapest of all strip counts by that model.
+int pick_blur_mfma_rows(const sift_hip_ctx *c, int nframes)
+{
+    if (c->blur_rows > 0) return std::min(c->blur_rows, c->H);
+    const int NB = (c->W + 15) / 16;
+    double best = 1e300;
+    int best_rows = c->H;
+    for (int k = 1; k <= c->H; k++) {
+        const int rows = (c->H + k - 1) / k;
+        if (rows < 8) break;
+        const int strips = (c->H + rows - 1) / rows;
+        const double waves = (double)((NB * strips + 15) / 16) * nframes;
+        const double rounds = waves > 4096.0 ? waves / 1024.0 : std::ceil(waves / 1024.0);
+        const double cost = (rows + 18) * rounds;
+        if (cost < best * 0.999) { best = cost; best_rows = rows; }
+    }
+    return best_rows;
+}
+
 // blur -> detect -> cull -> emit on device-resident frames
 int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_gradfull, sift::kp_t *d_kps,
                uint32_t *d_total, int th, hipStream_t s)
@@ -312,7 +335,14 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
     const int W = c->W, H = c->H, S = c->S;
     c->last_frames = nframes;
     HIP_TRY(hipMemsetAsync(c->d_listcount, 0, (size_t)nframes * 4, s));
-    {
+    // k_blur_mfma addresses a frame's pyr plane (4 bytes per pixel) through one 32-bit buffer descriptor
+    if (c->blur_mfma && c->npix * 4 < (1ull << 32)) {
+        StageTimer t(c, ST_BLUR, s);
+        const int rows = pick_blur_mfma_rows(c, nframes);
+        const int nstrips = (H + rows - 1) / rows, NB = (W + 15) / 16;
+        const int waves = (NB * nstrips + 15) / 16;
+        hipLaunchKernelGGL(sift::k_blur_mfma, dim3((waves + 3) / 4, nframes), dim3(512), 0, s, d_imgs, c->d_pyr, W, H, rows, nstrips);
+    } else {
         StageTimer t(c, ST_BLUR, s);
         const int rows = pick_blur_rows(c, nframes);
         // 64-thread blocks when a row has few dword columns, so small frames still spread over CUs
@@ -575,6 +605,16 @@ int sift_hip_set_blur_rows(sift_hip_ctx *c, int rows)
     if (int r = check_ctx(c)) return r;
     if (rows < 0) return fail(SIFT_HIP_EINVAL, "rows must be >= 0");
     c->blur_rows = rows;
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_set_blur_mfma(sift_hip_ctx *c, int on)
+{
+    if (int r = check_ctx(c)) return r;
+    c->blur_mfma = on != 0;
+    if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }   // a captured graph holds the old choice
+    c->gkey = sift_hip_ctx::GraphKey{};
+    c->gseen = 0;
     return SIFT_HIP_OK;
 }
 

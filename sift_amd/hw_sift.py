@@ -173,6 +173,10 @@ class SiftContext:
     def set_blur_rows(self, rows):
         check(self._lib.sift_hip_set_blur_rows(self._h, int(rows)))
 
+    def set_blur_mfma(self, on):
+        """comparison knob: False runs the blurs on the vector ALUs (k_blur) instead of the matrix cores"""
+        check(self._lib.sift_hip_set_blur_mfma(self._h, 1 if on else 0))
+
     def set_graph_frames(self, max_frames):
         check(self._lib.sift_hip_set_graph_frames(self._h, int(max_frames)))
 

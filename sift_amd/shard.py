@@ -19,10 +19,23 @@ def frame_seeds(first_seed, per_rank, rank):
     return [first_seed + rank * per_rank + i for i in range(per_rank)]
 
 
+def pick_device(local_rank, visible, share=False):
+    """device index of the rank with LOCAL_RANK `local_rank` when `visible` devices are visible to it:
+    its own when every rank sees the whole node, device 0 when a per-rank visibility mask leaves exactly
+    one; `share` (the gloo rehearsal on a one-GPU box) lets several ranks use one device"""
+    if visible < 1:
+        raise RuntimeError("rank with LOCAL_RANK %d sees no GPU" % local_rank)
+    if local_rank < visible:
+        return local_rank
+    if visible == 1 or share:
+        return local_rank % visible
+    raise RuntimeError("LOCAL_RANK %d but only %d GPUs visible" % (local_rank, visible))
+
+
 class DistEnv:
     """One process per GPU, launched by torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*)."""
 
-    def __init__(self, backend=None):
+    def __init__(self, backend=None, device=None):
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -36,8 +49,9 @@ class DistEnv:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
             self.backend = backend
             if backend == "nccl":
-                torch.cuda.set_device(self.local_rank)
-                self._device = torch.device("cuda", self.local_rank)
+                dev = self.local_rank if device is None else int(device)
+                torch.cuda.set_device(dev)
+                self._device = torch.device("cuda", dev)
             else:
                 self._device = torch.device("cpu")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

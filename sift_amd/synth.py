@@ -34,3 +34,30 @@ def synth_frame(seed, width, height):
                 n = np.repeat(np.repeat(n, 1 << s, axis=0), 1 << s, axis=1)[:height, :width]
             acc += np.uint32(w) * n
     return (acc // np.uint32(12)).astype(np.uint8)
+
+
+def synth_frames_torch(seeds, width, height, device="cpu"):
+    """The same frames as synth_frame, for a list of seeds, computed with torch on `device`
+    (int64 arithmetic masked to 32 bits) -> uint8 tensor [len(seeds), height, width]."""
+    import torch
+    M = 0xFFFFFFFF
+
+    def h32(x):
+        x = x ^ (x >> 16)
+        x = (x * 0x7FEB352D) & M
+        x = x ^ (x >> 15)
+        x = (x * 0x846CA68B) & M          # the product may wrap past 2^63: the low 32 bits are still right
+        x = x ^ (x >> 16)
+        return x
+
+    seed = torch.tensor([int(s) & M for s in seeds], dtype=torch.int64, device=device)[:, None, None]
+    acc = torch.zeros((len(seeds), height, width), dtype=torch.int64, device=device)
+    for s, w in _SCALES:
+        cy = torch.arange((height + (1 << s) - 1) >> s, dtype=torch.int64, device=device)[:, None]
+        cx = torch.arange((width + (1 << s) - 1) >> s, dtype=torch.int64, device=device)[None, :]
+        inner = h32(((cy * 0x9E3779B1) & M) + cx & M)
+        n = h32(seed ^ inner[None] ^ ((s * 0x85EBCA6B) & M)) & 0xFF
+        if s:
+            n = n.repeat_interleave(1 << s, dim=1).repeat_interleave(1 << s, dim=2)[:, :height, :width]
+        acc += w * n
+    return (acc // 12).to(torch.uint8)

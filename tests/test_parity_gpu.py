@@ -292,11 +292,14 @@ def test_strip_lengths_do_not_change_results(sift, orc):
     rk, rd, _ = orc.detect_and_compute(img)
     n = nvalid(rk)
     with sift.SiftContext(W, H) as ctx:
-        for rows in (1, 5, 6, 9, 17, 47, 48, 100, 479, 480, 1000):
-            ctx.set_blur_rows(rows)
-            kps, desc = ctx.sift_detect_and_compute(img)
-            assert (kps == rk).all() and (desc[:n] == rd[:n]).all(), "blur rows %d" % rows
+        for mfma in (True, False):                                  # k_blur_mfma, then both variants of k_blur
+            ctx.set_blur_mfma(mfma)
+            for rows in (1, 5, 6, 9, 17, 47, 48, 100, 479, 480, 1000):
+                ctx.set_blur_rows(rows)
+                kps, desc = ctx.sift_detect_and_compute(img)
+                assert (kps == rk).all() and (desc[:n] == rd[:n]).all(), "blur rows %d (mfma %r)" % (rows, mfma)
         ctx.set_blur_rows(0)
+        ctx.set_blur_mfma(True)
         for rows in (1, 4, 5, 12, 31, 32, 33, 500):
             ctx.set_detect_rows(rows)
             kps, desc = ctx.sift_detect_and_compute(img)
@@ -551,3 +554,21 @@ def test_detect_queue_drains_in_mid_strip(sift, orc):
                     m = ref["kp1"] > 0
                     assert (pl["eratio"][m] == ref["eratio"][m]).all()
             assert int((ref["kp1"] > 0).sum()) > 100                # with the smallest queue every group of rows that queued anything drains
+
+
+@pytest.mark.parametrize("W,H", [(640, 480), (324, 201), (148, 150), (1920, 1080), (36, 40), (4, 1)])
+def test_blur_on_vector_alus_and_on_matrix_cores(sift, orc, W, H):
+    """The blurs run on the matrix cores (k_blur_mfma, the default) or on the vector ALUs (k_blur, both
+    of its variants): G1, G2, G3 of either against the oracle, at widths that are and are not multiples
+    of the 16-pixel blocks of the MFMA kernel, and frames smaller than its 64-pixel operand window."""
+    img = orc.synth_frame(21, W, H)
+    g = orc.blur(img)
+    with sift.SiftContext(W, H) as ctx:
+        for mfma in (True, False):
+            ctx.set_blur_mfma(mfma)
+            for rows in (0, 7, 64):
+                ctx.set_blur_rows(rows)
+                ctx.sift_detect(img, want_grad=False)
+                pl = ctx.debug_planes(0)
+                for k, name in enumerate(("g1", "g2", "g3")):
+                    assert (pl[name] == g[k]).all(), (name, mfma, rows)
