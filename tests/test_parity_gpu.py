@@ -397,8 +397,11 @@ def test_bench_line_contract(sift):
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] * 1e-3 - 8) < 1e-6 * 8 + 1e-9
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
-    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert rf["bound"] in ("hbm", "mfma")
+    assert (rf["unit"], rf["peak"]) == (("GB/s", 8000.0) if rf["bound"] == "hbm" else ("TOP/s (i8)", 5000.0))
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf
+    assert d["checked_frames"] == 8 and d["end_to_end"]["sift_hip_batch"]["value"] > 0
+    assert d["end_to_end"]["sift_hip_batch_top"]["ms_per_call"]["p50"] > 0 and d["end_to_end"]["checked_frames"] == 16
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0 and cb["sample"]
     assert d["overlapped"]["outputs_equal_one_stream"] is True
@@ -572,3 +575,24 @@ def test_blur_on_vector_alus_and_on_matrix_cores(sift, orc, W, H):
                 pl = ctx.debug_planes(0)
                 for k, name in enumerate(("g1", "g2", "g3")):
                     assert (pl[name] == g[k]).all(), (name, mfma, rows)
+
+
+def test_bench_two_ranks_sharing_the_gpu(sift):
+    """`python bench.py --gpus 2` as a plain command: it starts its two ranks itself (gloo here, so that
+    both may use the one GPU of the box; RCCL on a real node), weak and strong scaling."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for scaling, per_gpu, total in (("weak", 8, 16), ("strong", 4, 8)):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--width", "640", "--height", "480",
+                            "--batch", "8", "--steps", "3", "--warmup", "1", "--scaling", scaling],
+                           capture_output=True, text=True, timeout=170, cwd=root, env=dict(os.environ, SIFT_BENCH_BACKEND="gloo"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["checked_frames"] == total
+        assert d["config"]["frames_per_step_per_gpu"] == per_gpu and d["config"]["frames_per_step"] == total
+        assert abs(d["value"] * d["ms_per_step"] * 1e-3 - total) < 1e-6 * total + 1e-9
+        assert "cpu_baseline" not in d and "other_configs" not in d
