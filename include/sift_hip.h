@@ -14,7 +14,10 @@
  *   - a context owns one device, one stream and persistent device scratch for
  *     `max_batch` frames (this replaces the per-call sds_alloc/sds_free of
  *     HW_SIFT.cpp:23-24,44-45).  A context is not thread-safe; distinct
- *     contexts are independent.
+ *     contexts are independent.  All calls on one context share that scratch, so
+ *     they must be ordered with respect to each other on the device: use one
+ *     stream per context (the *_dev calls take a stream argument; two calls of one
+ *     context on two streams race), or two contexts for two streams.
  *   - frame size is a run-time parameter of the context (the reference fixes
  *     WIDTH/HEIGHT at compile time, SIFTParameters.hpp:17-18).  width must be a
  *     multiple of 4; width >= 4, height >= 1.
@@ -88,7 +91,11 @@ int sift_hip_detect_and_compute(sift_hip_ctx *ctx, const uint8_t *img, sift_keyp
  * grad (width*height Grad_t) may be NULL when the caller does not want it. */
 int sift_hip_detect(sift_hip_ctx *ctx, const uint8_t *img, sift_grad *grad, sift_keypoint *kps, int contrastTh);
 
-/* compute_main_orientation, SIFT_Descriptor.hpp:12-14 / SIFT_Descriptor.cpp:18-103. */
+/* compute_main_orientation, SIFT_Descriptor.hpp:12-14 / SIFT_Descriptor.cpp:18-103.
+ * Supported planes: magGrad <= 32767 wherever angGrad is 1..8 (sift_detect produces at most 360).  The
+ * reference accumulates ap_int<16> MagGrad (:81), so a larger magnitude would count as negative there;
+ * this call and sift_hip_descriptor return SIFT_HIP_EINVAL for such a plane (the *_dev variants, which do
+ * not synchronise, leave the result unspecified). */
 int sift_hip_main_orientation(sift_hip_ctx *ctx, const sift_grad *grad, const sift_keypoint *kps, uint8_t *ori);
 
 /* compute_descriptor, SIFT_Descriptor.hpp:59-62 / SIFT_Descriptor.cpp:419-478. */

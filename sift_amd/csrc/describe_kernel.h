@@ -89,8 +89,10 @@ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)   // v_pk_add
 // Caller-supplied Grad_t planes (the stand-alone entry points) into the internal plane, so that
 // those calls take the quad sweep too.  The internal format holds magnitudes up to
 // DESC_MAX_MAG_PACKED in 16-bit bin halves; a larger one (sift_detect produces none) raises
-// *flag, and the call then runs the Grad_t kernel instead.  Codes outside 1..8 carry no weight
-// (:245-252), like code 0.
+// bit 0 of *flag, and the call then runs the Grad_t kernel instead; one above 32767, which the
+// reference's ap_int<16> MagGrad (:81) would count as negative in the orientation sum, raises bit 1 as
+// well: the host-buffer entry points refuse such a plane (SIFT_HIP_EINVAL) instead of returning an
+// orientation the reference would not.  Codes outside 1..8 carry no weight (:245-252), like code 0.
 // grid: x = ceil(W/4 / 256), y = ceil(H/4) groups of rows, z = frames; block = 256
 __global__ __launch_bounds__(256) void k_grad_pairs(const uint4 *__restrict__ grad, uint16_t *__restrict__ gradp,
                                                     uint32_t *__restrict__ flag, int W, int H)
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void k_grad_pairs(const uint4 *__restrict__ gr
     if (g >= W4) return;
     const uint4 *__restrict__ fin = grad + (size_t)blockIdx.z * (size_t)W4 * (size_t)H;
     uint32_t o[8];
-    bool big = false;
+    bool big = false, huge = false;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int y = blockIdx.y * 4 + r;
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(256) void k_grad_pairs(const uint4 *__restrict__ gr
             const uint32_t ang = px[p] & 0xffffu, mag = px[p] >> 16;
             const bool counts = ang >= 1u && ang <= 8u;
             big |= counts && mag > (uint32_t)DESC_MAX_MAG_PACKED;
+            huge |= counts && mag > 32767u;                            // the reference's ap_int<16> MagGrad (:81) would go negative
             w[p] = counts ? gradp_pack((int)ang, (int)(mag & 0x1ffu), p & 1) : 0u;
         }
         o[2 * r] = w[0] | w[1];
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void k_grad_pairs(const uint4 *__restrict__ gr
     uint4 *dst = reinterpret_cast<uint4 *>(gradp + gradp_frame_words(W, H) * (size_t)blockIdx.z + gradp_quad_word(blockIdx.y * 4, g, W4));
     dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
     dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
-    if (big) atomicOr(flag, 1u);
+    if (big) atomicOr(flag, huge ? 3u : 1u);
 }
 
 // grid: x = max_kp keypoints, y = frames; block = 64 (one wave)
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                                                  int max_kp, const uint32_t *__restrict__ gate, uint32_t gate_want)
 {
     // stand-alone calls launch this kernel once per gradient format; k_grad_pairs' flag says which runs
-    if (gate && *gate != gate_want) return;
+    if (gate && (*gate & 1u) != gate_want) return;
     constexpr bool PACK = GFMT == GRAD_PACKED16;
     constexpr int ROWS = PACK ? 40 : 80;         // rows that hold bins
     constexpr int LROWS = PACK ? 48 : 80;        // + circle id 10: spare rows of the quad sweep (never read)

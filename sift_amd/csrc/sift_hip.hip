@@ -441,6 +441,18 @@ int run_describe_planes(sift_hip_ctx *c, const sift_grad *d_grad, int nframes, c
     return run_describe<sift::GRAD_FULL32, MODE>(c, d_grad, nframes, d_kps, ori_in, ori_out, d_desc, s, c->d_gate, 1u);
 }
 
+// end of a host-buffer orientation / descriptor call: wait, then look at k_grad_pairs' flag
+int finish_planes_call(sift_hip_ctx *c, hipStream_t s)
+{
+    uint32_t flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, c->d_gate, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (flag & 2u)
+        return fail(SIFT_HIP_EINVAL, "gradient plane holds a counted magnitude above 32767: the reference's ap_int<16> MagGrad "
+                                     "(SIFT_Descriptor.cpp:81) would count it as negative; such planes are not supported");
+    return SIFT_HIP_OK;
+}
+
 int check_ctx(const sift_hip_ctx *c)
 {
     if (!c) return fail(SIFT_HIP_EINVAL, "null context");
@@ -886,8 +898,7 @@ int sift_hip_main_orientation(sift_hip_ctx *c, const sift_grad *grad, const sift
                                               c->d_ori, s))
         return r;
     HIP_TRY(hipMemcpyAsync(ori, c->d_ori, (size_t)c->max_kp, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return SIFT_HIP_OK;
+    return finish_planes_call(c, s);
 }
 
 int sift_hip_descriptor(sift_hip_ctx *c, const sift_grad *grad, const sift_keypoint *kps, const uint8_t *ori,
@@ -905,8 +916,7 @@ int sift_hip_descriptor(sift_hip_ctx *c, const sift_grad *grad, const sift_keypo
                                         c->d_ori, c->d_desc, s))
         return r;
     HIP_TRY(hipMemcpyAsync(desc, c->d_desc, (size_t)c->max_kp * 72 * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return SIFT_HIP_OK;
+    return finish_planes_call(c, s);
 }
 
 }  // extern "C"

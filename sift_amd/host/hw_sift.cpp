@@ -27,7 +27,8 @@ sift_hip_ctx *ctx()
 {
     if (!g_ctx) {
         if (sift_hip_create(&g_ctx, g_dev, g_w, g_h, MAX_KEYPOINTS, 1) != SIFT_HIP_OK) die("sift_hip_create");
-        atexit(sift_shutdown);
+        static bool registered = false;              // once per process, however often the context is recreated
+        if (!registered) { atexit(sift_shutdown); registered = true; }
     }
     return g_ctx;
 }

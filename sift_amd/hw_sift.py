@@ -52,6 +52,11 @@ class SiftContext:
         self.close()
 
     def __del__(self):
+        # prefer close() or the context manager; at interpreter shutdown the HIP runtime may already be
+        # torn down, so nothing is destroyed then (the process is about to release everything anyway)
+        import sys
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

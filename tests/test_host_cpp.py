@@ -104,3 +104,81 @@ def test_main_like_driver_reads_bmp(tmp_path, orc):
             idx = got[:, 0]
             assert len(idx) == min(n, 1000)
             assert (got[:, 1] == rk["x"][idx]).all() and (got[:, 2] == rk["y"][idx]).all()
+
+
+MAIN_SHAPED = r'''
+// A caller shaped like the reference's main.cpp, using INTEGRATION.md section 2 verbatim: the buffers of
+// main.cpp:18-32 from sift_alloc, the byte copy of :55-58, the call of :73, the sort and memcpy of :82-84,
+// the frees of :214-217.
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include "HW_SIFT.hpp"
+
+static bool CompareContrast(const Keypoint_t &a, const Keypoint_t &b) { return a.contrast > b.contrast; }   // main.cpp:9-12
+
+int main(int argc, char **argv)
+{
+    if (argc < 5) return 2;
+    const int w = atoi(argv[2]), h = atoi(argv[3]);
+    Pixel_t    *pSrcImageCam0   = (Pixel_t *)   sift_alloc((unsigned long)w * h);
+    Keypoint_t *pKeypoints      = (Keypoint_t *)sift_alloc(MAX_KEYPOINTS * sizeof(Keypoint_t));
+    Desc_t     *pDesc           = (Desc_t *)    sift_alloc(MAX_KEYPOINTS * DESC_SIZE * sizeof(Desc_t));
+    Keypoint_t *pFinalKeypoints = (Keypoint_t *)sift_alloc(MAX_FINAL_KEYPOINTS * sizeof(Keypoint_t));
+    if (!pSrcImageCam0 || !pKeypoints || !pDesc || !pFinalKeypoints) return 3;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f || fread(pSrcImageCam0, 1, (size_t)w * h, f) != (size_t)w * h) return 4;
+    fclose(f);
+    sift_set_frame_size(w, h);
+    sift_detect_and_compute(pSrcImageCam0, pKeypoints, pDesc, 15);                    // main.cpp:73
+    f = fopen(argv[4], "wb");                                                         // raster-order outputs, before the sort
+    fwrite(pKeypoints, sizeof(Keypoint_t), MAX_KEYPOINTS, f);
+    fwrite(pDesc, sizeof(Desc_t), (size_t)MAX_KEYPOINTS * DESC_SIZE, f);
+    std::sort(pKeypoints, pKeypoints + MAX_KEYPOINTS, CompareContrast);               // main.cpp:82
+    memcpy(pFinalKeypoints, pKeypoints, MAX_FINAL_KEYPOINTS * sizeof(Keypoint_t));    // main.cpp:84
+    fwrite(pFinalKeypoints, sizeof(Keypoint_t), MAX_FINAL_KEYPOINTS, f);
+    fclose(f);
+    int nKp = 0;                                                                      // main.cpp:112-129
+    for (int i = 0; i < MAX_FINAL_KEYPOINTS; i++) nKp += pFinalKeypoints[i].x > 0 && pFinalKeypoints[i].y > 0;
+    printf("%d final keypoints\n", nKp);
+    sift_free(pSrcImageCam0); sift_free(pKeypoints); sift_free(pDesc); sift_free(pFinalKeypoints);   // main.cpp:214-217
+    return 0;
+}
+'''
+
+
+def _build_main_shaped(tmp_path):
+    src = tmp_path / "main_shaped.cpp"
+    src.write_text(MAIN_SHAPED)
+    exe = tmp_path / "main_shaped"
+    libdir = os.path.join(ROOT, "sift_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src),
+                           "-L", libdir, "-lhw_sift", "-lsift_hip", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_main_cpp_shaped_caller_builds(tmp_path):
+    """the INTEGRATION.md section 2 recipe compiles and links against the two libraries as written"""
+    assert os.path.exists(_build_main_shaped(tmp_path))
+
+
+@pytest.mark.gpu
+def test_main_cpp_shaped_caller_runs(tmp_path, sift, orc):
+    exe = _build_main_shaped(tmp_path)
+    W, H, K = 1920, 1080, 10000
+    img = orc.synth_frame(3, W, H)
+    img.tofile(tmp_path / "frame.raw")
+    out = subprocess.run([str(exe), str(tmp_path / "frame.raw"), str(W), str(H), str(tmp_path / "out.bin")],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    raw = np.fromfile(tmp_path / "out.bin", np.uint8)
+    kps = raw[:K * 8].view(sift.KP_DTYPE)
+    desc = raw[K * 8:K * 8 + K * 72 * 4].view(np.uint32).reshape(K, 72)
+    final = raw[K * 8 + K * 72 * 4:].view(sift.KP_DTYPE)
+    rk, rd, _ = orc.detect_and_compute(img)
+    n = int((rk["contrast"] > 0).sum())
+    assert (kps == rk).all() and (desc[:n] == rd[:n]).all() and not desc[n:].any()
+    # std::sort is unstable: the sorted contrasts are determined, the order inside ties is not
+    assert len(final) == 1000 and (final["contrast"] == np.sort(rk["contrast"])[::-1][:1000]).all()
+    ref_top, _, nv = orc.select_top(rk, 1000)
+    assert ("%d final keypoints" % nv) in out.stdout

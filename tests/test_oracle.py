@@ -372,3 +372,41 @@ def test_oracle_translation_covariance(orc, dx, dy):
     assert len(ia) == len(ib) > 300
     assert (ka["x"][ia] + dx == kb["x"][ib]).all() and (ka["y"][ia] + dy == kb["y"][ib]).all()
     assert (ka["contrast"][ia] == kb["contrast"][ib]).all() and (da[ia] == db[ib]).all()
+
+
+def test_tables_against_the_reference_literals_read_independently(orc):
+    """A second reading of the reference's table literals that shares no code with
+    tools/derive_tables.py: the three Gaussian tables are parsed out of
+    DetectKeypoints.cpp:756-801 with a regular expression, quantised with exact rational
+    arithmetic (ap_fixed<16,1,AP_RND_ZERO>: nearest multiple of 2^-15, ties toward zero) and
+    compared with the oracle's integers; the masks of mask_all.hpp:8-78 and circle_mask.hpp:16-40
+    likewise.  Skipped where the reference tree is absent (the GPU box)."""
+    import re
+    from fractions import Fraction
+    src = "/root/reference/src"
+    if not os.path.isdir(src):
+        pytest.skip("reference tree not present")
+    text = open(os.path.join(src, "DetectKeypoints.cpp"), errors="replace").read()
+    live = text[:text.index("/*", text.index("ComputeGradientsHLS"))] if "ComputeGradientsHLS" in text else text
+    for which, n in ((1, 5), (2, 11), (3, 19)):
+        m = re.search(r"Mask_t\s+GaussianKernel%d\s*\[[^\]]*\]\s*\[[^\]]*\]\s*=\s*\{(.*?)\}\s*;" % which, live, re.S)
+        assert m, which
+        lits = re.findall(r"\d+\.\d+(?:[eE][-+]?\d+)?", m.group(1))
+        assert len(lits) == n * n, (which, len(lits))
+        q = []
+        for lit in lits:
+            v = Fraction(lit) * 32768                                # exact decimal value of the literal
+            fl = v.numerator // v.denominator
+            frac = v - fl
+            q.append(fl + (1 if frac > Fraction(1, 2) else 0))       # a tie would go toward zero (v >= 0): none occurs
+            assert frac != Fraction(1, 2)
+        got = orc.gauss_table(which)
+        assert (got.reshape(-1) == np.array(q)).all(), which
+    mtext = open(os.path.join(src, "mask_all.hpp"), errors="replace").read()
+    m = re.search(r"MaskAll\s*\[[^\]]*\]\s*\[[^\]]*\]\s*=\s*\{(.*?)\}\s*;", mtext, re.S)
+    bits = [int(float(t)) for t in re.findall(r"(?<![\w.])\d+(?:\.\d+)?(?![\w.])", re.sub(r"//[^\n]*", "", m.group(1)))]
+    assert len(bits) == 71 * 71 and (orc.mask_all().reshape(-1) == np.array(bits)).all()
+    ctext = open(os.path.join(src, "circle_mask.hpp"), errors="replace").read()
+    m = re.search(r"CircleMask\s*\[[^\]]*\]\s*=\s*\{(.*?)\}\s*;", ctext, re.S)
+    bits = [int(float(t)) for t in re.findall(r"(?<![\w.])\d+(?:\.\d+)?(?![\w.])", re.sub(r"//[^\n]*", "", m.group(1)))]
+    assert len(bits) == 625 and (orc.circle_mask().reshape(-1) == np.array(bits)).all()

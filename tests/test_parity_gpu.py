@@ -197,6 +197,17 @@ def test_caller_supplied_gradient_planes(sift, orc):
             assert (ori == ro).all(), (maxmag, maxang)
             d = ctx.compute_descriptor(grad, kps, ro)
             assert (d == orc.descriptor(grad, kps, ro)).all(), (maxmag, maxang)
+        # a counted magnitude above 32767 would be negative in the reference's ap_int<16> sum: refused
+        grad = np.zeros((H, W), sift.GRAD_DTYPE)
+        grad["ang"] = rng.integers(0, 9, (H, W))
+        grad["mag"] = rng.integers(0, 300, (H, W))
+        grad["mag"][100, 100], grad["ang"][100, 100] = 40000, 3
+        for call in (lambda: ctx.compute_main_orientation(grad, kps), lambda: ctx.compute_descriptor(grad, kps, ro)):
+            with pytest.raises(sift.SiftHipError) as e:
+                call()
+            assert e.value.code == -1 and "32767" in str(e.value)
+        grad["ang"][100, 100] = 0                                      # not counted: the plane is fine
+        assert (ctx.compute_main_orientation(grad, kps) == orc.main_orientation(grad, kps)).all()
         # worst case for the 16-bit bin halves of the fast kernel: every pixel 360, one direction
         grad = np.zeros((H, W), sift.GRAD_DTYPE)
         grad["ang"] = 2
