@@ -66,6 +66,20 @@ typedef struct sift_hip_ctx sift_hip_ctx;
  * largest number of frames one call may carry (>= 1). */
 int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int max_keypoints, int max_batch);
 
+/* The same with the descriptor geometry chosen.  SIFT_HIP_GEOMETRY_CAM0 is what the reference's code
+ * uses (WINDOW_SIZE 71, MASK_SIZE 25, XStart/YStart, MaskAll; SIFTParameters.hpp:34-44, circle_mask.hpp:7-40,
+ * mask_all.hpp:8-78) and what sift_hip_create gives.  SIFT_HIP_GEOMETRY_CAM1 uses the second set of tables the
+ * reference ships but never reads (DESC_WIN_SIZE_1 81, MASK_SIZE_1 29, XStartCam1/YStartCam1,
+ * CircleMaskCam1, MaskAll_81; SIFTParameters.hpp:46-55, circle_mask.hpp:12-13, :43-71, mask_all.hpp:161-241;
+ * SIFT_Descriptor.cpp:496 is an empty "CAM1" section).  Its semantics are DEFINED here as the Cam0 loops
+ * (SIFT_Descriptor.cpp:52-100, :196-253) with those constants substituted: orientation over 81 rows x 80
+ * columns (2 * radius, :70) of MaskAll_81, nine 29 x 29 circle histograms at (XStartCam1, YStartCam1).
+ * Only the orientation / descriptor stage depends on the geometry; keypoints do not. */
+#define SIFT_HIP_GEOMETRY_CAM0 0
+#define SIFT_HIP_GEOMETRY_CAM1 1
+int sift_hip_create_geometry(sift_hip_ctx **out, int device, int width, int height, int max_keypoints, int max_batch,
+                             int geometry);
+
 /* Replaces sds_free (main.cpp:214-217, HW_SIFT.cpp:44-45). */
 void sift_hip_destroy(sift_hip_ctx *ctx);
 

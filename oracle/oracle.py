@@ -115,35 +115,48 @@ def sift_detect(img, contrast_th=15, max_kp=MAX_KEYPOINTS, planes=False, want_gr
     return res
 
 
-def main_orientation(grad, kps):
+def main_orientation(grad, kps, geometry=0):
+    """geometry 0 = Cam0 (the reference's code), 1 = Cam1 (its tables, semantics defined in sift_oracle.c)"""
     grad = np.ascontiguousarray(grad)
     H, W = grad.shape
     kps = np.ascontiguousarray(kps)
     ori = np.zeros(len(kps), np.uint8)
-    lib().orc_main_orientation(_p(grad), C.c_int(W), C.c_int(H), _p(kps), C.c_int(len(kps)), _p(ori))
+    lib().orc_main_orientation_geo(_p(grad), C.c_int(W), C.c_int(H), _p(kps), C.c_int(len(kps)), _p(ori), C.c_int(geometry))
     return ori
 
 
-def descriptor(grad, kps, ori):
+def descriptor(grad, kps, ori, geometry=0):
     grad = np.ascontiguousarray(grad)
     H, W = grad.shape
     kps = np.ascontiguousarray(kps)
     ori = np.ascontiguousarray(ori, np.uint8)
     desc = np.zeros((len(kps), DESC_SIZE), np.uint32)
-    lib().orc_descriptor(_p(grad), C.c_int(W), C.c_int(H), _p(kps), _p(ori), C.c_int(len(kps)), _p(desc))
+    lib().orc_descriptor_geo(_p(grad), C.c_int(W), C.c_int(H), _p(kps), _p(ori), C.c_int(len(kps)), _p(desc), C.c_int(geometry))
     return desc
 
 
-def detect_and_compute(img, contrast_th=15):
+def detect_and_compute(img, contrast_th=15, geometry=0):
     """-> (kps[10000], desc[10000,72], total)."""
     img = np.ascontiguousarray(img, np.uint8)
     H, W = img.shape
     kps = np.zeros(MAX_KEYPOINTS, KP_DTYPE)
     desc = np.zeros((MAX_KEYPOINTS, DESC_SIZE), np.uint32)
-    f = lib().orc_detect_and_compute
+    f = lib().orc_detect_and_compute_geo
     f.restype = C.c_int
-    total = f(_p(img), C.c_int(W), C.c_int(H), _p(kps), _p(desc), C.c_int(contrast_th))
+    total = f(_p(img), C.c_int(W), C.c_int(H), _p(kps), _p(desc), C.c_int(contrast_th), C.c_int(geometry))
     return kps, desc, total
+
+
+def geometry_masks(geometry):
+    """-> (window, radius, circle mask [m, m], xstart[9], ystart[9], orientation mask [window, window])"""
+    win, rad, m = ((71, 35, 25), (81, 40, 29))[geometry]
+    cm = np.zeros(m * m, np.uint8)
+    lib().orc_circle_mask_geo(C.c_int(geometry), _p(cm))
+    ma = np.zeros(win * win, np.uint8)
+    lib().orc_mask_all_geo(C.c_int(geometry), _p(ma))
+    xs = ((45, 32, 14, 1, 1, 14, 32, 45, 23), (52, 37, 15, 0, 0, 15, 37, 52, 26))[geometry]
+    ys = ((32, 45, 45, 32, 14, 1, 1, 14, 23), (37, 52, 52, 37, 15, 0, 0, 15, 26))[geometry]
+    return win, rad, cm.reshape(m, m), xs, ys, ma.reshape(win, win)
 
 
 def fnv1a(buf):

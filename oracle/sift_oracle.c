@@ -79,6 +79,44 @@ void orc_mask_all(uint8_t out[71 * 71])
                     out[(ORC_YSTART[n] + i) * 71 + ORC_XSTART[n] + j] = 1;
 }
 
+/* Descriptor geometry.  0 = Cam0, the only one the reference's code uses (window 71, radius 35,
+ * 25x25 circle mask, XStart/YStart, MaskAll).  1 = Cam1: the reference only ships its tables
+ * (DESC_WIN_SIZE_1 81, MASK_SIZE_1 29, SIFTParameters.hpp:46-55; CircleMaskCam1, XStartCam1/YStartCam1,
+ * circle_mask.hpp:12-13, :43-71; MaskAll_81, mask_all.hpp:161-241) and an empty "CAM1" section
+ * (SIFT_Descriptor.cpp:496), so its semantics are DEFINED here as the Cam0 loops below with those
+ * constants substituted -- in particular the orientation loop still runs over 2 * radius columns (:70),
+ * i.e. 80 of the 81, although MaskAll_81's last column is not empty.  Parity unpinned by construction. */
+typedef struct {
+    int window, radius, msize;
+    const unsigned char *xs, *ys, *lo, *hi;
+} orc_geometry;
+static const orc_geometry ORC_GEO[2] = {
+    {71, 35, 25, ORC_XSTART, ORC_YSTART, ORC_CIRCLE_LO, ORC_CIRCLE_HI},
+    {81, 40, 29, ORC_XSTART_CAM1, ORC_YSTART_CAM1, ORC_CIRCLE_CAM1_LO, ORC_CIRCLE_CAM1_HI},
+};
+
+/* circle mask of a geometry as msize x msize bytes */
+static void geo_circle_mask(const orc_geometry *g, uint8_t *out)
+{
+    for (int i = 0; i < g->msize; i++)
+        for (int j = 0; j < g->msize; j++)
+            out[i * g->msize + j] = (j >= g->lo[i] && j < g->hi[i]) ? 1 : 0;
+}
+
+/* MaskAll (geometry 0, mask_all.hpp:8-78) / MaskAll_81 (geometry 1, mask_all.hpp:161-241) as window x window bytes */
+void orc_mask_all_geo(int geometry, uint8_t *out)
+{
+    if (geometry == 0) { orc_mask_all(out); return; }
+    for (int r = 0; r < 81; r++)
+        for (int c = 0; c < 81; c++)
+            out[r * 81 + c] = (uint8_t)((ORC_MASKALL81[r][c >> 5] >> (c & 31)) & 1u);
+}
+
+void orc_circle_mask_geo(int geometry, uint8_t *out)
+{
+    geo_circle_mask(&ORC_GEO[geometry != 0], out);
+}
+
 /* ------------------------------------------------------------------- blur */
 
 /* GaussianBlurHLS + FilterKernelOperator1/2/3 + RoundToInt
@@ -348,21 +386,23 @@ static inline orc_grad grad_lin(const orc_grad *g, int W, int H, long idx)
 }
 
 /* compute_main_orientation + ComputeMainOrientation
- * (SIFT_Descriptor.cpp:18-103, :107-130): 71 rows x 70 columns (:70). */
-void orc_main_orientation(const orc_grad *grad, int W, int H, const orc_keypoint *kps, int n, uint8_t *ori)
+ * (SIFT_Descriptor.cpp:18-103, :107-130): window rows x 2 * radius columns (:70) -- 71 x 70 for Cam0. */
+void orc_main_orientation_geo(const orc_grad *grad, int W, int H, const orc_keypoint *kps, int n, uint8_t *ori, int geometry)
 {
-    uint8_t mask[71 * 71];
-    orc_mask_all(mask);
+    const orc_geometry *g = &ORC_GEO[geometry != 0];
+    const int WS = g->window, R = g->radius;
+    uint8_t mask[81 * 81];
+    orc_mask_all_geo(geometry != 0, mask);
     for (int k = 0; k < n; k++) {
         int px = kps[k].x, py = kps[k].y;
         uint8_t m = 0;
         if (px > 0 && py > 0) {                                     /* :52 */
             int hist[9] = {0};
-            for (int y = py - ORC_RADIUS; y <= py + ORC_RADIUS; y++) {
-                int line = y - py + ORC_RADIUS;
-                for (int x = 0; x < 2 * ORC_RADIUS; x++) {          /* :70 */
-                    orc_grad a = grad_lin(grad, W, H, (long)y * W + px - ORC_RADIUS + x);
-                    if (a.ang < 9) hist[a.ang] += (int)(int16_t)a.mag * mask[line * 71 + x];
+            for (int y = py - R; y <= py + R; y++) {
+                int line = y - py + R;
+                for (int x = 0; x < 2 * R; x++) {                   /* :70 */
+                    orc_grad a = grad_lin(grad, W, H, (long)y * W + px - R + x);
+                    if (a.ang < 9) hist[a.ang] += (int)(int16_t)a.mag * mask[line * WS + x];
                 }
             }
             int best = 0;                                            /* :110-126 */
@@ -373,27 +413,34 @@ void orc_main_orientation(const orc_grad *grad, int W, int H, const orc_keypoint
     }
 }
 
+void orc_main_orientation(const orc_grad *grad, int W, int H, const orc_keypoint *kps, int n, uint8_t *ori)
+{
+    orc_main_orientation_geo(grad, W, H, kps, n, ori, 0);
+}
+
 /* compute_descriptor = compute_histograms_hls + reorder_histograms_hls
  * (SIFT_Descriptor.cpp:419-478, :151-278, :295-398).  Keypoints with x==0 or
  * y==0 (the padding) have an uninitialised descriptor in the reference
  * (:194-196, :266-274); it is defined as all-zero here. */
-void orc_descriptor(const orc_grad *grad, int W, int H, const orc_keypoint *kps, const uint8_t *ori,
-                    int n, uint32_t *desc)
+void orc_descriptor_geo(const orc_grad *grad, int W, int H, const orc_keypoint *kps, const uint8_t *ori,
+                        int n, uint32_t *desc, int geometry)
 {
-    uint8_t cm[625];
-    orc_circle_mask(cm);
+    const orc_geometry *g = &ORC_GEO[geometry != 0];
+    const int MS = g->msize, R = g->radius;
+    uint8_t cm[29 * 29];
+    geo_circle_mask(g, cm);
     for (int k = 0; k < n; k++) {
         int px = kps[k].x, py = kps[k].y;
         uint32_t hin[9][9];
         memset(hin, 0, sizeof hin);
         uint32_t *out = desc + (size_t)k * ORC_DESC_SIZE;
         if (!(px > 0 && py > 0)) { memset(out, 0, ORC_DESC_SIZE * 4); continue; }   /* :196 */
-        for (int i = 0; i < 25; i++)                                 /* :211-234 */
-            for (int j = 0; j < 25; j++)
+        for (int i = 0; i < MS; i++)                                 /* :211-234 */
+            for (int j = 0; j < MS; j++)
                 for (int c = 0; c < 9; c++) {
-                    int wy = ORC_YSTART[c] + i, wx = ORC_XSTART[c] + j;
-                    orc_grad a = grad_lin(grad, W, H, (long)(py - ORC_RADIUS + wy) * W + px - ORC_RADIUS + wx);
-                    if (a.ang < 9) hin[c][a.ang] += (uint32_t)cm[i * 25 + j] * a.mag;
+                    int wy = g->ys[c] + i, wx = g->xs[c] + j;
+                    orc_grad a = grad_lin(grad, W, H, (long)(py - R + wy) * W + px - R + wx);
+                    if (a.ang < 9) hin[c][a.ang] += (uint32_t)cm[i * MS + j] * a.mag;
                 }
         /* :245-252 keep codes 1..8 as bins 0..7; :346-380 rotate by the main
          * orientation with 3-bit wrap: out[n][(b - m) & 7] = in[(m + n) & 7][b] */
@@ -406,16 +453,27 @@ void orc_descriptor(const orc_grad *grad, int W, int H, const orc_keypoint *kps,
     }
 }
 
+void orc_descriptor(const orc_grad *grad, int W, int H, const orc_keypoint *kps, const uint8_t *ori,
+                    int n, uint32_t *desc)
+{
+    orc_descriptor_geo(grad, W, H, kps, ori, n, desc, 0);
+}
+
 /* sift_detect_and_compute (HW_SIFT.cpp:16-50) */
-int orc_detect_and_compute(const uint8_t *img, int W, int H, orc_keypoint *kps, uint32_t *desc, int contrastTh)
+int orc_detect_and_compute_geo(const uint8_t *img, int W, int H, orc_keypoint *kps, uint32_t *desc, int contrastTh, int geometry)
 {
     orc_grad *grad = malloc((size_t)W * H * sizeof(orc_grad));
     uint8_t *ori = malloc(ORC_MAX_KEYPOINTS);
     int total = orc_sift_detect(img, W, H, grad, kps, contrastTh);                 /* :29 */
-    orc_main_orientation(grad, W, H, kps, ORC_MAX_KEYPOINTS, ori);                 /* :40 */
-    orc_descriptor(grad, W, H, kps, ori, ORC_MAX_KEYPOINTS, desc);                 /* :41 */
+    orc_main_orientation_geo(grad, W, H, kps, ORC_MAX_KEYPOINTS, ori, geometry);   /* :40 */
+    orc_descriptor_geo(grad, W, H, kps, ori, ORC_MAX_KEYPOINTS, desc, geometry);   /* :41 */
     free(grad); free(ori);
     return total;
+}
+
+int orc_detect_and_compute(const uint8_t *img, int W, int H, orc_keypoint *kps, uint32_t *desc, int contrastTh)
+{
+    return orc_detect_and_compute_geo(img, W, H, kps, desc, contrastTh, 0);
 }
 
 /* ------------------------------------------------------- synthetic frames */

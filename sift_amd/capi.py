@@ -23,7 +23,7 @@ GRAD_DTYPE = np.dtype([("ang", "<u2"), ("mag", "<u2")])
 
 # every symbol include/sift_hip.h declares (tests check the library exports all)
 EXPORTS = (
-    "sift_hip_create", "sift_hip_destroy", "sift_hip_last_error", "sift_hip_device_count",
+    "sift_hip_create", "sift_hip_create_geometry", "sift_hip_destroy", "sift_hip_last_error", "sift_hip_device_count",
     "sift_hip_host_alloc", "sift_hip_host_free",
     "sift_hip_detect_and_compute", "sift_hip_detect", "sift_hip_main_orientation", "sift_hip_descriptor",
     "sift_hip_select_top", "sift_hip_select_top_dev", "sift_hip_gray_from_bgr", "sift_hip_gray_from_bgr_dev",
@@ -74,6 +74,7 @@ def load_library():
     lib.sift_hip_destroy.restype = None
     lib.sift_hip_destroy.argtypes = [vp]
     lib.sift_hip_create.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32]
+    lib.sift_hip_create_geometry.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32, i32]
     lib.sift_hip_detect_and_compute.argtypes = [vp, vp, vp, vp, i32]
     lib.sift_hip_detect.argtypes = [vp, vp, vp, vp, i32]
     lib.sift_hip_main_orientation.argtypes = [vp, vp, vp, vp]

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                                                  uint32_t *__restrict__ desc, const uint2 *__restrict__ tab,
                                                  int n2, int n2pad, int ntab, const void *__restrict__ qtab,
                                                  int qa, int qu, int qb, const uint32_t *__restrict__ total, int W, int H,
-                                                 int max_kp, const uint32_t *__restrict__ gate, uint32_t gate_want)
+                                                 int max_kp, const uint32_t *__restrict__ gate, uint32_t gate_want,
+                                                 int radius, int qrow4, const uint2 *__restrict__ spec, int nspec)
 {
     // stand-alone calls launch this kernel once per gradient format; k_grad_pairs' flag says which runs
     if (gate && (*gate & 1u) != gate_want) return;
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     constexpr int U = DESC_UNROLL;
     __shared__ __align__(16) uint32_t hist[LROWS][32];
     __shared__ uint32_t fin[80];
+    __shared__ uint32_t corr[8];                 // orientation corrections of the geometry (spec), per direction code
 
     const int lane = threadIdx.x;
     // slots blockIdx.x, + gridDim.x, ...; in the fused mode `total` (k_emit's count) tells which
@@ -193,11 +195,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         uint4 *z = reinterpret_cast<uint4 *>(&hist[0][0]);
 #pragma unroll
         for (int i = 0; i < LROWS * 32 / 4 / 64; i++) z[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        if (nspec && lane < 8) corr[lane] = 0u;
     }
     __syncthreads();
 
     const long npix = (long)W * H;
-    const long origin = (long)(py - 35) * W + (px - 35);
+    const long origin = (long)(py - radius) * W + (px - radius);
     const int W4 = W >> 2;
     const char *__restrict__ gplane = reinterpret_cast<const char *>(gradv) +
                                       (size_t)blockIdx.y * (PACK ? gradp_frame_words(W, H) * 2 : (size_t)npix * 4);
@@ -418,9 +421,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     // the window is rows py-35..py+35 at columns px-35..px+35 of a linearly addressed plane
     if constexpr (PACK) {
         // quad sweep: the 19 aligned quads per row that cover the window must lie in their rows
-        const int x0 = px - 35, y0 = py - 35;
+        const int x0 = px - radius, y0 = py - radius;
         const int xph = x0 & 3, yph = y0 & 3;        // one table per alignment of the window in the plane
-        if (qtab && x0 - xph >= 0 && x0 - xph + 76 <= W && y0 >= 0 && py + 35 < H) {
+        if (qtab && x0 - xph >= 0 && x0 - xph + qrow4 <= W && y0 >= 0 && py + radius < H) {
             const char *gq = gplane + gradp_quad_word(y0 - yph, (x0 - xph) >> 2, W4) * 2;
             const char *tq = reinterpret_cast<const char *>(qtab) + (size_t)(yph * 4 + xph) * ((size_t)qa * 8u + (size_t)qu * 2u + (size_t)qb * 4u);
             if constexpr (NA + NU + NB > 0) quad_static(gq, tq);
@@ -429,9 +432,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             sweep(std::true_type{});
         }
     } else {
-        const bool inside = origin >= 0 && origin + 70L * W + 70 < npix;
+        const bool inside = origin >= 0 && origin + 2L * radius * W + 2 * radius < npix;
         if (inside) sweep(std::false_type{});
         else sweep(std::true_type{});
+    }
+    // Orientation corrections (none for the reference's geometry): the few pixels whose weight in the
+    // orientation sum is not "once per union pixel" -- union pixels in the column the 2 * radius loop bound
+    // (:70) leaves out count -1, pixels of the orientation mask outside the union +1 -- one lane each.
+    if (MODE != DESC_GIVEN_ORI && nspec) {
+        if (lane < nspec) {
+            const uint2 e = spec[lane];
+            const uint32_t g = gather(std::true_type{}, e.x, true);
+            uint32_t a, v;
+            if constexpr (PACK) { v = g & 0x1ffu; a = ((g >> 9) & 3u) * 2u + ((g >> 15) & 1u); }
+            else { a = (g & 0xffffu) - 1u; v = a < 8u ? (g >> 16) : 0u; a &= 7u; }
+            atomicAdd(&corr[a], e.y ? 0u - v : v);
+        }
     }
     __syncthreads();
 
@@ -472,6 +488,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         uint32_t v = 0u - fin[72 + a];
 #pragma unroll
         for (int n = 0; n < 9; n++) v += fin[n * 8 + a];
+        if (nspec) v += corr[a];
         // (int)v > 0 is the reference's test; the key orders by value, then by smaller a
         uint32_t key = ((int)v > 0) ? ((v << 3) | (uint32_t)(7 - a)) : 0u;
         // max over the 8 lanes of a group: lanes ^1 and ^2 by quad permutes; after those the two

@@ -54,32 +54,57 @@ int fail(int code, const char *what, hipError_t e = hipSuccess)
 enum { ST_BLUR = 0, ST_DETECT, ST_CULL, ST_EMIT, ST_DESCRIBE };
 const char *const kStageNames[SIFT_HIP_NSTAGES] = {"k_blur", "k_detect", "k_cull", "k_emit", "k_describe"};
 
-// Union-pixel table of the 71x71 descriptor window for frames `W` wide (see
-// describe_kernel.h): two-circle pixels first (n2, padded to n2pad), then the rest.
+// Descriptor geometry.  0 = Cam0, the one the reference's code uses (window 71, radius 35, 25x25 circle
+// mask, XStart/YStart, MaskAll = the union of the nine circles).  1 = Cam1: the reference ships only its
+// tables (SIFTParameters.hpp:46-55, circle_mask.hpp:12-13, :43-71, mask_all.hpp:161-241); its semantics
+// are defined as the Cam0 loops with those constants substituted, so the orientation window
+// is 81 rows x 80 columns (2 * radius, SIFT_Descriptor.cpp:70) of MaskAll_81, which is the union of the
+// nine Cam1 circles plus 8 pixels.
+struct Geometry {
+    int window, radius, msize;
+    const unsigned char *xs, *ys, *lo, *hi;
+    int nextra;
+    const unsigned char (*extra)[2];      // {row, column} of orientation-mask pixels outside the union
+};
+const Geometry kGeometry[2] = {
+    {71, 35, 25, SIFT_XSTART, SIFT_YSTART, SIFT_CIRCLE_LO, SIFT_CIRCLE_HI, 0, nullptr},
+    {81, 40, 29, SIFT_XSTART_CAM1, SIFT_YSTART_CAM1, SIFT_CIRCLE_CAM1_LO, SIFT_CIRCLE_CAM1_HI, 8, SIFT_MASKALL81_EXTRA},
+};
+constexpr int MAXWIN = 81;
+
+// circle ids of every window pixel: c1 = first circle, c2 = second (10 = none); false if a pixel lies in three
+bool circle_ids(const Geometry &g, int (&c1)[MAXWIN][MAXWIN], int (&c2)[MAXWIN][MAXWIN])
+{
+    for (int y = 0; y < MAXWIN; y++)
+        for (int x = 0; x < MAXWIN; x++) c1[y][x] = c2[y][x] = 10;
+    for (int n = 0; n < 9; n++)
+        for (int i = 0; i < g.msize; i++)
+            for (int j = g.lo[i]; j < g.hi[i]; j++) {
+                const int y = g.ys[n] + i, x = g.xs[n] + j;
+                if (c1[y][x] == 10) c1[y][x] = n;
+                else if (c2[y][x] == 10) c2[y][x] = n;
+                else return false;
+            }
+    return true;
+}
+
+// Union-pixel table of the descriptor window for frames `W` wide (see describe_kernel.h): two-circle
+// pixels first (n2, padded to n2pad), then the rest.
 // kmax = the most pixels of one circle (or of the overlap set) that fall to one lane.
 struct WindowTable { std::vector<uint2> e; int n2 = 0, n2pad = 0, kmax = 0; };
-WindowTable build_window_table(int W)
+WindowTable build_window_table(int W, const Geometry &g)
 {
-    int owner[71][71][2];
-    int cnt[71][71];
-    memset(cnt, 0, sizeof cnt);
-    for (int n = 0; n < 9; n++)
-        for (int i = 0; i < 25; i++)
-            for (int j = SIFT_CIRCLE_LO[i]; j < SIFT_CIRCLE_HI[i]; j++) {
-                int y = SIFT_YSTART[n] + i, x = SIFT_XSTART[n] + j;
-                if (cnt[y][x] < 2) owner[y][x][cnt[y][x]] = n;
-                cnt[y][x]++;
-            }
+    int c1[MAXWIN][MAXWIN], c2[MAXWIN][MAXWIN];
+    if (!circle_ids(g, c1, c2)) return WindowTable{};   // would break Hist = sum Hin - Ov; checked in create()
     WindowTable t;
     std::vector<uint2> one;
-    for (int y = 0; y < 71; y++)
-        for (int x = 0; x < 71; x++) {
-            if (cnt[y][x] > 2) return WindowTable{};   // would break Hist = sum Hin - Ov; checked in create()
+    for (int y = 0; y < g.window; y++)
+        for (int x = 0; x < g.window; x++) {
             const uint32_t off2 = (uint32_t)(y * W + x) * 2u;
-            if (cnt[y][x] == 2)
-                t.e.push_back(make_uint2(off2, (uint32_t)owner[y][x][0] << 9 | (uint32_t)owner[y][x][1] << 25));
-            else if (cnt[y][x] == 1)
-                one.push_back(make_uint2(off2, (uint32_t)owner[y][x][0] << 9));
+            if (c2[y][x] != 10)
+                t.e.push_back(make_uint2(off2, (uint32_t)c1[y][x] << 9 | (uint32_t)c2[y][x] << 25));
+            else if (c1[y][x] != 10)
+                one.push_back(make_uint2(off2, (uint32_t)c1[y][x] << 9));
         }
     t.n2 = (int)t.e.size();
     while (t.e.size() % 64) t.e.push_back(make_uint2(0, 0));   // never read: the loops stop at n2
@@ -99,9 +124,26 @@ WindowTable build_window_table(int W)
     return t;
 }
 
+// Pixels whose weight in the orientation sum differs from "once per union pixel" (Hist = sum Hin - Ov):
+// union pixels in columns the orientation loop does not reach (x >= 2 * radius, SIFT_Descriptor.cpp:70) count
+// -1, orientation-mask pixels outside the union +1.  None for Cam0 (column 70 of MaskAll is empty); 22 + 8
+// for Cam1.  Entry: x = byte offset in a 2-byte plane as in the window table, y = 1 to subtract.
+std::vector<uint2> build_special_table(int W, const Geometry &g)
+{
+    int c1[MAXWIN][MAXWIN], c2[MAXWIN][MAXWIN];
+    std::vector<uint2> t;
+    if (!circle_ids(g, c1, c2)) return t;
+    for (int y = 0; y < g.window; y++)
+        for (int x = 2 * g.radius; x < g.window; x++)
+            if (c1[y][x] != 10) t.push_back(make_uint2((uint32_t)(y * W + x) * 2u, 1u));
+    for (int i = 0; i < g.nextra; i++)
+        if (g.extra[i][1] < 2 * g.radius) t.push_back(make_uint2((uint32_t)(g.extra[i][0] * W + g.extra[i][1]) * 2u, 0u));
+    return t;
+}
+
 // Quad table of the describe kernel's fast path (describe_kernel.h): for each alignment of the
 // window in the plane (variant = (row of the window's first row in its group of four) * 4 + column
-// phase), the aligned 4-pixel quads of the 71-row window that hold a union pixel; quads with a
+// phase), the aligned 4-pixel quads of the window's rows that hold a union pixel; quads with a
 // two-circle pixel first (part A: qa entries after padding, 8 bytes each), then quads that lie in one
 // circle with all four pixels (part U: qu entries, 2 bytes each: (quad * 4 + row in the group) |
 // group of rows << 7 | circle id << 12), then the rest (part B: qb entries, 4 bytes each: group of
@@ -109,31 +151,25 @@ WindowTable build_window_table(int W)
 // All parts are ordered by address in the row-interleaved plane (detect_kernel.h), so consecutive
 // lanes read consecutive 8-byte pieces.
 struct QuadTable { std::vector<uint8_t> bytes; int qa = 0, qu = 0, qb = 0, kmax = 0; };
-QuadTable build_quad_table(int W)
+QuadTable build_quad_table(int W, const Geometry &g)
 {
-    int c1[71][71], c2[71][71];
-    for (int y = 0; y < 71; y++)
-        for (int x = 0; x < 71; x++) c1[y][x] = c2[y][x] = 10;     // 10 = not in the union
-    for (int n = 0; n < 9; n++)
-        for (int i = 0; i < 25; i++)
-            for (int j = SIFT_CIRCLE_LO[i]; j < SIFT_CIRCLE_HI[i]; j++) {
-                int y = SIFT_YSTART[n] + i, x = SIFT_XSTART[n] + j;
-                if (c1[y][x] == 10) c1[y][x] = n; else c2[y][x] = n;
-            }
+    int c1[MAXWIN][MAXWIN], c2[MAXWIN][MAXWIN];
+    if (!circle_ids(g, c1, c2)) return QuadTable{};
+    const int WS = g.window, QR = (WS + 2) / 4 + 1;     // aligned quads that cover a window row at any phase: 19 / 21
     struct Quad { int y, q, a[4], b[4]; };          // y = window row + row phase: row from the base group's first row
     std::vector<Quad> A[16], U[16], B[16];
     size_t na = 0, nu = SIZE_MAX;
     for (int v = 0; v < 16; v++) {
         const int ph = v & 3, yph = v >> 2;
-        for (int y = 0; y < 71; y++)
-            for (int q = 0; q < 19; q++) {
+        for (int y = 0; y < WS; y++)
+            for (int q = 0; q < QR; q++) {
                 Quad e;
                 e.y = y + yph; e.q = q;
                 bool any = false, two = false, uniform = true;
                 for (int p = 0; p < 4; p++) {
                     const int x = q * 4 + p - ph;                  // window column of this pixel
                     e.a[p] = e.b[p] = 10;
-                    if (x >= 0 && x < 71) { e.a[p] = c1[y][x]; e.b[p] = c2[y][x]; }
+                    if (x >= 0 && x < WS) { e.a[p] = c1[y][x]; e.b[p] = c2[y][x]; }
                     any |= e.a[p] != 10;
                     two |= e.b[p] != 10;
                     uniform &= e.a[p] != 10 && e.a[p] == e.a[0];
@@ -232,6 +268,8 @@ struct sift_hip_ctx {
     size_t bgr_cap = 0;
     uint2 *d_tab = nullptr;
     uint32_t *d_qtab = nullptr;           // quad table (build_quad_table)
+    uint2 *d_spec = nullptr;              // orientation corrections of the geometry (build_special_table)
+    int nspec = 0, radius = 35, qrow4 = 76; // window radius and bytes^-1: 4 x aligned quads per window row (describe kernel)
     uint32_t *d_gate = nullptr;           // k_grad_pairs' flag: which of the two describe kernels of a stand-alone call runs
     int ntab = 0, n2 = 0, n2pad = 0, qa = 0, qu = 0, qb = 0;
     bool quad_sweep = true;               // false: every window through the pixel sweep (sift_hip_set_quad_sweep)
@@ -410,16 +448,16 @@ int run_describe(sift_hip_ctx *c, const void *d_grad, int nframes, const sift::k
     // the reference's masks give 5 + 9 + 2 steps of 64 quads: straight-line variant
     if (GFMT == sift::GRAD_PACKED16 && (int)grid.x == c->max_kp && c->qa == 5 * 64 && c->qu == 9 * 64 && c->qb == 2 * 64)
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false, 5, 9, 2>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec);
     else if ((int)grid.x == c->max_kp)
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec);
     else if (GFMT == sift::GRAD_PACKED16 && c->qa == 5 * 64 && c->qu == 9 * 64 && c->qb == 2 * 64)
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true, 5, 9, 2>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec);
     else
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec);
     HIP_TRY(hipGetLastError());
     return SIFT_HIP_OK;
 }
@@ -508,8 +546,15 @@ const char *sift_hip_stage_name(int stage)
 
 int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int max_keypoints, int max_batch)
 {
+    return sift_hip_create_geometry(out, device, width, height, max_keypoints, max_batch, SIFT_HIP_GEOMETRY_CAM0);
+}
+
+int sift_hip_create_geometry(sift_hip_ctx **out, int device, int width, int height, int max_keypoints, int max_batch, int geometry)
+{
     if (!out) return fail(SIFT_HIP_EINVAL, "out is null");
     *out = nullptr;
+    if (geometry != SIFT_HIP_GEOMETRY_CAM0 && geometry != SIFT_HIP_GEOMETRY_CAM1) return fail(SIFT_HIP_EINVAL, "unknown descriptor geometry");
+    const Geometry &geo = kGeometry[geometry];
     if (width < 4 || (width & 3) || height < 1 || width > 65532 || height > 65535)
         return fail(SIFT_HIP_EINVAL, "width must be a multiple of 4 in [4,65532], height in [1,65535]");
     if (max_keypoints < 1 || max_batch < 1) return fail(SIFT_HIP_EINVAL, "max_keypoints and max_batch must be >= 1");
@@ -521,10 +566,12 @@ int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int m
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(SIFT_HIP_ENODEV, "device is not gfx950 (the library carries gfx950 code only)");
 
-    const WindowTable wt = build_window_table(width);
+    const WindowTable wt = build_window_table(width, geo);
     const std::vector<uint2> &tab = wt.e;
     if (tab.empty()) return fail(SIFT_HIP_EINVAL, "circle tables overlap three-fold");
-    const QuadTable qt = build_quad_table(width);
+    const QuadTable qt = build_quad_table(width, geo);
+    const std::vector<uint2> spec = build_special_table(width, geo);
+    if (spec.size() > 64) return fail(SIFT_HIP_EINVAL, "more than 64 orientation corrections");
     // 16-bit bins of the describe kernel: a column's bin takes kmax pixels, and the reduction adds
     // 2 columns before widening (describe_kernel.h)
     if (2L * std::max(wt.kmax, qt.kmax) * sift::DESC_MAX_MAG_PACKED >= 65536)
@@ -557,6 +604,9 @@ int sift_hip_create(sift_hip_ctx **out, int device, int width, int height, int m
     A((void **)&c->d_tab, tab.size() * sizeof(uint2));
     c->ntab = (int)tab.size(); c->n2 = wt.n2; c->n2pad = wt.n2pad;
     c->qa = qt.qa; c->qu = qt.qu; c->qb = qt.qb;
+    c->radius = geo.radius; c->qrow4 = ((geo.window + 2) / 4 + 1) * 4; c->nspec = (int)spec.size();
+    A((void **)&c->d_spec, std::max<size_t>(1, spec.size()) * sizeof(uint2));
+    if (e == hipSuccess && !spec.empty()) e = hipMemcpy(c->d_spec, spec.data(), spec.size() * sizeof(uint2), hipMemcpyHostToDevice);
     A((void **)&c->d_gate, 4);
     A((void **)&c->d_qtab, qt.bytes.size());
     if (e == hipSuccess) e = hipMemcpy(c->d_qtab, qt.bytes.data(), qt.bytes.size(), hipMemcpyHostToDevice);
@@ -575,7 +625,7 @@ void sift_hip_destroy(sift_hip_ctx *c)
     DevGuard g(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_img, c->d_pyr, c->d_list, c->d_listcount, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_gradp,
-                    c->d_gradfull, c->d_final, c->d_findex, c->d_nvalid, c->d_tfinal, c->d_tindex, c->d_tdesc, c->d_tnvalid, c->d_bgr, c->d_kps, c->d_desc, c->d_total, c->d_total_ctx, c->d_ori, c->d_tab, c->d_qtab, c->d_gate};
+                    c->d_gradfull, c->d_final, c->d_findex, c->d_nvalid, c->d_tfinal, c->d_tindex, c->d_tdesc, c->d_tnvalid, c->d_bgr, c->d_kps, c->d_desc, c->d_total, c->d_total_ctx, c->d_ori, c->d_tab, c->d_qtab, c->d_gate, c->d_spec};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &ps : c->prof)
         for (int i = 0; i < SIFT_HIP_NSTAGES; i++)
@@ -1171,8 +1221,8 @@ int sift_hip_detect_and_compute_static(int device, const uint8_t *d_imgs, int nf
         // plane offsets, so they are rebuilt on the host and copied to the front of the array.  The
         // copy is ordered on `stream` after whatever earlier call still reads the old tables, and the
         // host waits for it (the vectors go away); this step cannot run under stream capture.
-        const WindowTable wt = build_window_table(width);
-        const QuadTable qt = build_quad_table(width);
+        const WindowTable wt = build_window_table(width, kGeometry[0]);
+        const QuadTable qt = build_quad_table(width, kGeometry[0]);
         if (wt.e.empty()) return fail(SIFT_HIP_EINVAL, "circle tables overlap three-fold");
         if (2L * std::max(wt.kmax, qt.kmax) * sift::DESC_MAX_MAG_PACKED >= 65536)
             return fail(SIFT_HIP_EINVAL, "descriptor window too large for 16-bit lane bins");

@@ -31,13 +31,15 @@ def _dp(p):
 class SiftContext:
     """One device + stream + persistent scratch (sift_hip_create)."""
 
-    def __init__(self, width, height, device=0, max_keypoints=MAX_KEYPOINTS, max_batch=1):
+    def __init__(self, width, height, device=0, max_keypoints=MAX_KEYPOINTS, max_batch=1, geometry=0):
+        """geometry: 0 = Cam0 (the reference's code), 1 = Cam1 (its second set of descriptor tables)"""
         self._lib = load_library()
         self.width, self.height = int(width), int(height)
         self.max_keypoints, self.max_batch, self.device = int(max_keypoints), int(max_batch), int(device)
+        self.geometry = int(geometry)
         h = C.c_void_p()
-        check(self._lib.sift_hip_create(C.byref(h), self.device, self.width, self.height, self.max_keypoints,
-                                        self.max_batch))
+        check(self._lib.sift_hip_create_geometry(C.byref(h), self.device, self.width, self.height, self.max_keypoints,
+                                                 self.max_batch, self.geometry))
         self._h = h
 
     def close(self):

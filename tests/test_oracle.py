@@ -186,20 +186,19 @@ def test_oracle_stages_equal_numpy_restatement(orc, W, H, seed):
     assert not k["contrast"][n:].any() and not k["x"][n:].any() and not k["y"][n:].any()
 
 
-def np_descriptor(grad, kps, orc):
-    cm = orc.circle_mask().astype(np.int64)
-    ma = orc.mask_all().astype(np.int64)
-    xs = [45, 32, 14, 1, 1, 14, 32, 45, 23]
-    ys = [32, 45, 45, 32, 14, 1, 1, 14, 23]
+def np_descriptor(grad, kps, orc, geometry=0):
+    W, R, cm, xs, ys, ma = orc.geometry_masks(geometry)
+    M = cm.shape[0]
+    cm, ma = cm.astype(np.int64), ma.astype(np.int64)
     ori = np.zeros(len(kps), np.uint8)
     desc = np.zeros((len(kps), 72), np.uint32)
     for k, kp in enumerate(kps):
         x, y = int(kp["x"]), int(kp["y"])
         if not (x > 0 and y > 0):
             continue
-        win = grad[y - 35:y + 36, x - 35:x + 36]
+        win = grad[y - R:y + R + 1, x - R:x + R + 1]
         hist = np.zeros(9, np.int64)
-        np.add.at(hist, win["ang"][:, :70].astype(int), win["mag"][:, :70].astype(np.int64) * ma[:, :70])
+        np.add.at(hist, win["ang"][:, :2 * R].astype(int), win["mag"][:, :2 * R].astype(np.int64) * ma[:, :2 * R])
         m = 0
         best = 0
         for i in range(1, 9):
@@ -208,7 +207,7 @@ def np_descriptor(grad, kps, orc):
         ori[k] = m
         hin = np.zeros((9, 9), np.int64)
         for n in range(9):
-            w = win[ys[n]:ys[n] + 25, xs[n]:xs[n] + 25]
+            w = win[ys[n]:ys[n] + M, xs[n]:xs[n] + M]
             np.add.at(hin[n], w["ang"].astype(int), w["mag"].astype(np.int64) * cm)
         hin = hin[:, 1:]
         for n in range(9):
@@ -218,19 +217,24 @@ def np_descriptor(grad, kps, orc):
     return ori, desc
 
 
-def test_oracle_descriptor_equals_numpy_restatement(orc):
+@pytest.mark.parametrize("geometry", [0, 1])
+def test_oracle_descriptor_equals_numpy_restatement(orc, geometry):
+    """geometry 0 = the reference's code (Cam0); 1 = its Cam1 tables in the same loops (semantics defined
+    in oracle/sift_oracle.c: parity unpinned by construction)"""
     img = orc.synth_frame(3, 256, 256)
     ref = orc.sift_detect(img)
     kps = ref["kps"]
     n = int((kps["contrast"] > 0).sum())
     assert n >= 50
-    ori = orc.main_orientation(ref["grad"], kps)
-    desc = orc.descriptor(ref["grad"], kps, ori)
-    o2, d2 = np_descriptor(ref["grad"], kps[:n + 3], orc)
+    ori = orc.main_orientation(ref["grad"], kps, geometry)
+    desc = orc.descriptor(ref["grad"], kps, ori, geometry)
+    o2, d2 = np_descriptor(ref["grad"], kps[:n + 3], orc, geometry)
     assert (ori[:n + 3] == o2).all()
     assert (desc[:n + 3] == d2).all()
     assert not desc[n:].any() and not ori[n:].any()
     assert len(set(ori[:n].tolist())) >= 4          # the rotation path is exercised
+    rk, rd, _ = orc.detect_and_compute(img, geometry=geometry)
+    assert (rk == kps).all() and (rd == desc).all()
 
 
 def test_rotation_eight_behaves_like_zero(orc):
@@ -410,3 +414,14 @@ def test_tables_against_the_reference_literals_read_independently(orc):
     m = re.search(r"CircleMask\s*\[[^\]]*\]\s*=\s*\{(.*?)\}\s*;", ctext, re.S)
     bits = [int(float(t)) for t in re.findall(r"(?<![\w.])\d+(?:\.\d+)?(?![\w.])", re.sub(r"//[^\n]*", "", m.group(1)))]
     assert len(bits) == 625 and (orc.circle_mask().reshape(-1) == np.array(bits)).all()
+    # the Cam1 tables (circle_mask.hpp:12-13, :43-71, mask_all.hpp:161-241)
+    win, rad, cm1, xs1, ys1, ma1 = orc.geometry_masks(1)
+    m = re.search(r"CircleMaskCam1\s*\[[^\]]*\]\s*=\s*\{(.*?)\}\s*;", ctext, re.S)
+    bits = [int(t) for t in re.findall(r"\d+", re.sub(r"//[^\n]*", "", m.group(1)))]
+    assert len(bits) == 841 and (cm1.reshape(-1) == np.array(bits)).all()
+    m = re.search(r"MaskAll_81\s*\[81\]\s*\[81\]\s*=\s*\{(.*?)\}\s*;", mtext, re.S)
+    bits = [int(t) for t in re.findall(r"\d+", re.sub(r"//[^\n]*", "", m.group(1)))]
+    assert len(bits) == 81 * 81 and (ma1.reshape(-1) == np.array(bits)).all()
+    for name, want in (("XStartCam1", xs1), ("YStartCam1", ys1)):
+        m = re.search(name + r"\s*\[9\]\s*=\s*\{(.*?)\}", ctext, re.S)
+        assert tuple(int(t) for t in re.findall(r"\d+", m.group(1))) == tuple(want)

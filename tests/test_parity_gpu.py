@@ -607,3 +607,60 @@ def test_bench_two_ranks_sharing_the_gpu(sift):
         assert d["config"]["frames_per_step_per_gpu"] == per_gpu and d["config"]["frames_per_step"] == total
         assert abs(d["value"] * d["ms_per_step"] * 1e-3 - total) < 1e-6 * total + 1e-9
         assert "cpu_baseline" not in d and "other_configs" not in d
+
+
+def test_cam1_geometry(sift, orc):
+    """the reference's second set of descriptor tables (81 x 81 window, 29 x 29 circle mask,
+    XStartCam1 / YStartCam1, MaskAll_81), which its code never reads; semantics = the Cam0 loops with those
+    constants (oracle/sift_oracle.c, geometry 1).  Fused call, stand-alone calls with keypoints anywhere in
+    the frame (windows that leave the plane), every rotation code, the pixel sweep, and a batch large
+    enough for the grouped-slot kernel -- all against the oracle.  Keypoints do not depend on the geometry."""
+    import torch
+    for W, H, seed in ((640, 480, 1), (324, 201, 3), (1920, 1080, 2)):
+        img = orc.synth_frame(seed, W, H)
+        rk, rd, total = orc.detect_and_compute(img, geometry=1)
+        rk0, rd0, _ = orc.detect_and_compute(img)
+        n = nvalid(rk)
+        assert (rk == rk0).all() and n > 0 and (rd[:n] != rd0[:n]).any()
+        with sift.SiftContext(W, H, geometry=1) as ctx:
+            kps, desc = ctx.sift_detect_and_compute(img)
+            assert (kps == rk).all() and (desc[:n] == rd[:n]).all() and not desc[n:].any(), (W, H)
+            ctx.set_quad_sweep(False)
+            kps, desc = ctx.sift_detect_and_compute(img)
+            assert (kps == rk).all() and (desc[:n] == rd[:n]).all() and not desc[n:].any(), (W, H)
+            ctx.set_quad_sweep(True)
+            if W > 640:
+                continue
+            grad = orc.sift_detect(img)["grad"]
+            rng = np.random.default_rng(seed)
+            ck = np.zeros(10000, sift.KP_DTYPE)
+            m = 700
+            ck["x"][:m] = rng.integers(0, W, m)
+            ck["y"][:m] = rng.integers(0, H, m)
+            ck["contrast"][:m] = 7
+            ck[3] = (0, 17, 9)
+            ck[4] = (W - 1, H - 1, 9)
+            ro = orc.main_orientation(grad, ck, 1)
+            assert (ctx.compute_main_orientation(grad, ck) == ro).all()
+            assert (ro[:m] != orc.main_orientation(grad, ck)[:m]).any()      # the geometry matters
+            for o in (ro, rng.integers(0, 9, 10000).astype(np.uint8)):
+                assert (ctx.compute_descriptor(grad, ck, o) == orc.descriptor(grad, ck, o, 1)).all()
+            big = grad.copy()                                               # a plane the internal format cannot hold
+            big["mag"][::7, ::5] = 5000
+            ro = orc.main_orientation(big, ck, 1)
+            assert (ctx.compute_main_orientation(big, ck) == ro).all()
+            assert (ctx.compute_descriptor(big, ck, ro) == orc.descriptor(big, ck, ro, 1)).all()
+    W, H, B, K = 320, 240, 40, 10000
+    imgs = np.stack([orc.synth_frame(500 + s, W, H) for s in range(B)])
+    with sift.SiftContext(W, H, max_batch=B, geometry=1) as ctx:
+        d_img = torch.from_numpy(imgs).cuda()
+        d_kps = torch.full((B, K, 2), -1, dtype=torch.int32, device="cuda")
+        d_desc = torch.full((B, K, 72), -1, dtype=torch.int32, device="cuda")
+        ctx.detect_and_compute_dev(d_img, B, d_kps, d_desc)
+        ctx.sync()
+        kps = d_kps.cpu().numpy().view(sift.KP_DTYPE).reshape(B, K)
+        desc = d_desc.cpu().numpy().view(np.uint32)
+        for b in range(B):
+            rk, rd, _ = orc.detect_and_compute(imgs[b], geometry=1)
+            n = nvalid(rk)
+            assert (kps[b] == rk).all() and (desc[b, :n] == rd[:n]).all() and not desc[b, n:].any(), b

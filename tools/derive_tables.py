@@ -14,6 +14,10 @@ and writes the derived integer data this repo ships:
   * XStart / YStart      -- circle_mask.hpp:7-8.
   * MaskAll              -- mask_all.hpp:8-78; checked here to equal the union of
     the nine circles placed at (XStart, YStart), so only that fact is shipped.
+  * Cam1 geometry        -- CircleMaskCam1 (29x29) row spans and XStartCam1 / YStartCam1
+    (circle_mask.hpp:12-13, :43-71) and MaskAll_81 (mask_all.hpp:161-241).  MaskAll_81 is NOT the
+    union of the nine Cam1 circles: it holds 8 more pixels (checked here).  The oracle gets the
+    mask itself (81 rows of bits), the product the union fact plus those 8 pixels.
 
 Outputs (identical data, two consumers that must not depend on each other):
   oracle/oracle_tables.h        (CPU oracle, test infrastructure)
@@ -112,6 +116,35 @@ def mask_all_table():
     return [v[r * 71:(r + 1) * 71] for r in range(71)]
 
 
+def cam1_tables():
+    text = _live_text(os.path.join(REF, "circle_mask.hpp"))
+    xs = int_list(_braced_block(text, r"ap_uint<8>\s+XStartCam1\s*\[9\]\s*=\s*\{"))
+    ys = int_list(_braced_block(text, r"ap_uint<8>\s+YStartCam1\s*\[9\]\s*=\s*\{"))
+    cm = int_list(_braced_block(text, r"ap_uint<8>\s+CircleMaskCam1\s*\[29\*29\]\s*=\s*\{"))
+    assert len(xs) == 9 and len(ys) == 9 and len(cm) == 841 and set(cm) <= {0, 1}
+    spans = []
+    for r in range(29):
+        row = cm[r * 29:(r + 1) * 29]
+        ones = [i for i, v in enumerate(row) if v]
+        assert ones == list(range(ones[0], ones[-1] + 1)), "row is not a single run"
+        spans.append((ones[0], ones[-1] + 1))
+    mt = _live_text(os.path.join(REF, "mask_all.hpp"))
+    v = int_list(_braced_block(mt, r"ap_uint<16>\s+MaskAll_81\s*\[81\]\s*\[81\]\s*=\s*\{"))
+    assert len(v) == 81 * 81 and set(v) <= {0, 1}
+    ma = [v[r * 81:(r + 1) * 81] for r in range(81)]
+    cnt = [[0] * 81 for _ in range(81)]
+    for n in range(9):
+        for i in range(29):
+            for j in range(29):
+                if cm[i * 29 + j]:
+                    cnt[ys[n] + i][xs[n] + j] += 1
+    assert max(map(max, cnt)) == 2, "a Cam1 pixel lies in more than two circles"
+    assert all(ma[r][c] for r in range(81) for c in range(81) if cnt[r][c]), "MaskAll_81 misses a union pixel"
+    extra = [(r, c) for r in range(81) for c in range(81) if ma[r][c] and not cnt[r][c]]
+    assert len(extra) == 8
+    return xs, ys, spans, ma, extra
+
+
 def derive():
     g = gaussian_tables()
     xs, ys, cm, spans = circle_tables()
@@ -154,6 +187,27 @@ def emit(prefix, guard, role, qual="static const"):
     L.append(qual + " unsigned char %s_CIRCLE_HI[25] = {%s};" % (prefix, ",".join(str(b) for _, b in spans)))
     L.append("/* mask_all.hpp:8-78 equals the union of the nine circles at (XSTART,YSTART)")
     L.append(" * (checked by the generator); it is rebuilt from that at start-up. */")
+    xs1, ys1, spans1, ma1, extra1 = cam1_tables()
+    L.append("/* Cam1 geometry: circle_mask.hpp:12-13 */")
+    L.append(qual + " unsigned char %s_XSTART_CAM1[9] = {%s};" % (prefix, ",".join(map(str, xs1))))
+    L.append(qual + " unsigned char %s_YSTART_CAM1[9] = {%s};" % (prefix, ",".join(map(str, ys1))))
+    L.append("/* circle_mask.hpp:43-71: row i of the 29x29 mask is 1 on [lo,hi) */")
+    L.append(qual + " unsigned char %s_CIRCLE_CAM1_LO[29] = {%s};" % (prefix, ",".join(str(a) for a, _ in spans1)))
+    L.append(qual + " unsigned char %s_CIRCLE_CAM1_HI[29] = {%s};" % (prefix, ",".join(str(b) for _, b in spans1)))
+    if prefix == "ORC":
+        L.append("/* mask_all.hpp:161-241: MaskAll_81, row r = bits 0..80 of three words (bit c of word c / 32) */")
+        rows = []
+        for r in range(81):
+            w = [0, 0, 0]
+            for c in range(81):
+                if ma1[r][c]:
+                    w[c // 32] |= 1 << (c % 32)
+            rows.append("{0x%08xu,0x%08xu,0x%08xu}" % tuple(w))
+        L.append(qual + " unsigned int %s_MASKALL81[81][3] = {%s};" % (prefix, ",".join(rows)))
+    else:
+        L.append("/* mask_all.hpp:161-241: MaskAll_81 = the union of the nine Cam1 circles + these 8 pixels {row, column}")
+        L.append(" * (checked by the generator) */")
+        L.append(qual + " unsigned char %s_MASKALL81_EXTRA[8][2] = {%s};" % (prefix, ",".join("{%d,%d}" % e for e in extra1)))
     L.append("#endif")
     return "\n".join(L) + "\n"
 
