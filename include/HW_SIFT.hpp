@@ -30,3 +30,11 @@ int sift_select_final_keypoints(const Keypoint_t *pKeypoints, Keypoint_t *pFinal
 // of 4; bottomUp != 0 for BMP's row order) to WIDTH x HEIGHT gray bytes on the device, with the weights
 // of cv::imread(..., CV_LOAD_IMAGE_GRAYSCALE).
 void sift_gray_from_bgr(const uint8_t *pBgr, long pitch, int bottomUp, Pixel_t *pGray);
+// Descriptor geometry of the entry points: 0 = Cam0 (default; what the reference's code computes),
+// 1 = Cam1 (the reference's second set of tables, which its code never reads: DESC_WIN_SIZE_1, MASK_SIZE_1,
+// CircleMaskCam1, XStartCam1 / YStartCam1, MaskAll_81).  Drops the cached device context.
+void sift_set_geometry(int geometry);
+// Fills DMatch_t (SIFTParameters.hpp:122-128; the reference declares the type and has no matcher): for each of the
+// nQuery descriptor rows the train row of smallest L1 distance (integer, as the struct's comment asks), ties to
+// the smaller index; nQuery, nTrain <= 32767.
+void sift_match(const Desc_t *pQueryDesc, int nQuery, const Desc_t *pTrainDesc, int nTrain, DMatch_t *pMatches);

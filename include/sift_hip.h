@@ -56,6 +56,13 @@ typedef struct {
     uint16_t magGrad; /* floor(sqrt(gx^2+gy^2)) */
 } sift_grad;
 
+/* DMatch_t, SIFTParameters.hpp:122-128 (8 bytes) */
+typedef struct {
+    uint32_t distance; /* integer where OpenCV has a float */
+    int16_t queryIdx;  /* "querryIdx" in the reference */
+    int16_t trainIdx;
+} sift_dmatch;
+
 typedef struct sift_hip_ctx sift_hip_ctx;
 
 /* ---- life cycle -------------------------------------------------------- */
@@ -144,6 +151,16 @@ int sift_hip_batch_top(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const
                        sift_keypoint *final_kps, uint32_t *final_index, uint32_t *final_desc, uint32_t *nvalid,
                        int contrastTh);
 
+/* Brute-force matcher for DMatch_t (SIFTParameters.hpp:122-128).  NO REFERENCE CODE: the reference declares
+ * the type (and links OpenCV's features2d / flann, .cproject:93-94) but never matches; SURVEY.md 8(f)4 lists a
+ * matcher as an unpinned extension.  Semantics chosen to fit the struct: cv::BFMatcher(NORM_L1).match() on raw
+ * 72-word descriptor rows -- matches[q] = { sum over j of |query[q][j] - train[t][j]|, q, t } for the train row t
+ * of smallest distance (ties: smaller t); { 0xffffffff, q, -1 } when ntrain is 0.  nquery, ntrain <= 32767.
+ * Distances are 32-bit like the field: supported are rows whose distances stay below 2^32 (the words
+ * compute_descriptor produces stay below 2^18, so 72 of them cannot reach that). */
+int sift_hip_match(sift_hip_ctx *ctx, const uint32_t *query_desc, int nquery, const uint32_t *train_desc, int ntrain,
+                   sift_dmatch *matches);
+
 /* The ingest step of main.cpp:51-58 for colour frames: 24-bit BGR rows (as in a BMP: `pitch` bytes
  * apart, a multiple of 4, 0 = 3*width; bottom_up != 0 when the first stored row is the bottom one)
  * to the width*height gray bytes the entry points above take, with the fixed-point weights of
@@ -187,6 +204,11 @@ int sift_hip_descriptor_dev(sift_hip_ctx *ctx, const sift_grad *d_grad, int nfra
 int sift_hip_select_top_dev(sift_hip_ctx *ctx, const sift_keypoint *d_kps, int nframes, int nfinal,
                             sift_keypoint *d_final, uint32_t *d_index, uint32_t *d_nvalid, const uint32_t *d_desc,
                             uint32_t *d_final_desc, void *stream);
+
+/* sift_hip_match on device buffers, for `npairs` independent pairs of descriptor sets: pair p matches rows
+ * d_query[p * nquery ...] against d_train[p * ntrain ...] into d_matches[p * nquery ...] (16-byte aligned arrays). */
+int sift_hip_match_dev(sift_hip_ctx *ctx, const uint32_t *d_query_desc, int nquery, const uint32_t *d_train_desc, int ntrain,
+                       int npairs, sift_dmatch *d_matches, void *stream);
 
 /* sift_hip_gray_from_bgr on device buffers: d_bgr nframes*height*pitch bytes (4-byte aligned) ->
  * d_gray nframes*width*height, e.g. straight into the d_imgs of the calls above. */

@@ -188,3 +188,15 @@ def bgr2gray(bgr, W, bottom_up=False):
     gray = np.zeros((H, W), np.uint8)
     lib().orc_bgr2gray(_p(bgr), C.c_int(W), C.c_int(H), C.c_long(pitch), C.c_int(int(bool(bottom_up))), _p(gray))
     return gray
+
+
+DMATCH_DTYPE = np.dtype([("distance", "<u4"), ("queryIdx", "<i2"), ("trainIdx", "<i2")])
+
+
+def match(query_desc, train_desc):
+    """DMatch_t per query row: nearest train row in the L1 sense (defined semantics; the reference has the type only)"""
+    q = np.ascontiguousarray(query_desc, np.uint32).reshape(-1, DESC_SIZE)
+    t = np.ascontiguousarray(train_desc, np.uint32).reshape(-1, DESC_SIZE)
+    out = np.zeros(len(q), DMATCH_DTYPE)
+    lib().orc_match(_p(q), C.c_int(len(q)), _p(t), C.c_int(len(t)), _p(out))
+    return out

@@ -549,3 +549,26 @@ void orc_bgr2gray(const uint8_t *bgr, int W, int H, long pitch, int bottom_up, u
             gray[(size_t)y * W + x] = (uint8_t)((row[3 * x] * 1868 + row[3 * x + 1] * 9617 + row[3 * x + 2] * 4899 + 8192) >> 14);
     }
 }
+
+/* ---- matcher for DMatch_t (SIFTParameters.hpp:122-128) ------------------------------------------
+ * The reference has the type only.  Defined semantics (see include/sift_hip.h): per query row the train
+ * row of smallest L1 distance, ties to the smaller index; {0xffffffff, q, -1} without train rows. */
+typedef struct { uint32_t distance; int16_t queryIdx, trainIdx; } orc_dmatch;
+void orc_match(const uint32_t *query, int nquery, const uint32_t *train, int ntrain, orc_dmatch *out)
+{
+    for (int q = 0; q < nquery; q++) {
+        uint64_t best = UINT64_MAX;
+        int bt = -1;
+        for (int t = 0; t < ntrain; t++) {
+            uint64_t d = 0;
+            for (int j = 0; j < ORC_DESC_SIZE; j++) {
+                uint32_t a = query[(size_t)q * ORC_DESC_SIZE + j], b = train[(size_t)t * ORC_DESC_SIZE + j];
+                d += a > b ? a - b : b - a;
+            }
+            if (d < best) { best = d; bt = t; }
+        }
+        out[q].distance = bt < 0 ? 0xffffffffu : (uint32_t)best;
+        out[q].queryIdx = (int16_t)q;
+        out[q].trainIdx = (int16_t)bt;
+    }
+}

@@ -20,6 +20,7 @@ NSTAGES = 5
 # Keypoint_t (SIFTParameters.hpp:79-85) and Grad_t (:88-92)
 KP_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("contrast", "<u4")])
 GRAD_DTYPE = np.dtype([("ang", "<u2"), ("mag", "<u2")])
+DMATCH_DTYPE = np.dtype([("distance", "<u4"), ("queryIdx", "<i2"), ("trainIdx", "<i2")])   # DMatch_t (:122-128)
 
 # every symbol include/sift_hip.h declares (tests check the library exports all)
 EXPORTS = (
@@ -27,7 +28,7 @@ EXPORTS = (
     "sift_hip_host_alloc", "sift_hip_host_free",
     "sift_hip_detect_and_compute", "sift_hip_detect", "sift_hip_main_orientation", "sift_hip_descriptor",
     "sift_hip_select_top", "sift_hip_select_top_dev", "sift_hip_gray_from_bgr", "sift_hip_gray_from_bgr_dev",
-    "sift_hip_batch", "sift_hip_batch_top", "sift_hip_detect_and_compute_dev", "sift_hip_detect_dev",
+    "sift_hip_match", "sift_hip_match_dev", "sift_hip_batch", "sift_hip_batch_top", "sift_hip_detect_and_compute_dev", "sift_hip_detect_dev",
     "sift_hip_main_orientation_dev", "sift_hip_descriptor_dev", "sift_hip_sync", "sift_hip_debug_planes",
     "sift_hip_set_profiling", "sift_hip_stage_ms", "sift_hip_stage_name", "sift_hip_set_blur_rows", "sift_hip_set_blur_mfma", "sift_hip_set_detect_rows", "sift_hip_set_detect_queue", "sift_hip_detect_and_compute_static", "sift_hip_static_scratch_needed", "sift_hip_set_graph_frames", "sift_hip_set_quad_sweep",
 )
@@ -89,6 +90,8 @@ def load_library():
     lib.sift_hip_select_top_dev.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.sift_hip_gray_from_bgr.argtypes = [vp, vp, C.c_long, i32, vp]
     lib.sift_hip_gray_from_bgr_dev.argtypes = [vp, vp, i32, C.c_long, i32, vp, vp]
+    lib.sift_hip_match.argtypes = [vp, vp, i32, vp, i32, vp]
+    lib.sift_hip_match_dev.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
     lib.sift_hip_sync.argtypes = [vp]
     lib.sift_hip_debug_planes.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     lib.sift_hip_set_profiling.argtypes = [vp, i32]

@@ -26,9 +26,11 @@
 #include "describe_kernel.h"
 #include "select_kernel.h"
 #include "ingest_kernel.h"
+#include "match_kernel.h"
 
 static_assert(sizeof(sift_keypoint) == 8 && sizeof(sift::kp_t) == 8, "Keypoint_t is 8 bytes");
 static_assert(sizeof(sift_grad) == 4, "Grad_t is 4 bytes");
+static_assert(sizeof(sift_dmatch) == 8 && sizeof(sift::dmatch_t) == 8, "DMatch_t is 8 bytes");
 
 namespace {
 
@@ -264,6 +266,8 @@ struct sift_hip_ctx {
     sift::kp_t *d_tfinal = nullptr;       // sift_hip_batch_top: selected keypoints of the chunks in flight (lazily allocated)
     uint32_t *d_tindex = nullptr, *d_tdesc = nullptr, *d_tnvalid = nullptr;
     size_t top_cap = 0;
+    uint8_t *d_match = nullptr;           // staging of sift_hip_match (lazily allocated)
+    size_t match_cap = 0;
     uint8_t *d_bgr = nullptr;             // staging of sift_hip_gray_from_bgr (lazily allocated)
     size_t bgr_cap = 0;
     uint2 *d_tab = nullptr;
@@ -625,7 +629,7 @@ void sift_hip_destroy(sift_hip_ctx *c)
     DevGuard g(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_img, c->d_pyr, c->d_list, c->d_listcount, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_gradp,
-                    c->d_gradfull, c->d_final, c->d_findex, c->d_nvalid, c->d_tfinal, c->d_tindex, c->d_tdesc, c->d_tnvalid, c->d_bgr, c->d_kps, c->d_desc, c->d_total, c->d_total_ctx, c->d_ori, c->d_tab, c->d_qtab, c->d_gate, c->d_spec};
+                    c->d_gradfull, c->d_final, c->d_findex, c->d_nvalid, c->d_tfinal, c->d_tindex, c->d_tdesc, c->d_tnvalid, c->d_bgr, c->d_match, c->d_kps, c->d_desc, c->d_total, c->d_total_ctx, c->d_ori, c->d_tab, c->d_qtab, c->d_gate, c->d_spec};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &ps : c->prof)
         for (int i = 0; i < SIFT_HIP_NSTAGES; i++)
@@ -836,6 +840,52 @@ int sift_hip_select_top_dev(sift_hip_ctx *c, const sift_keypoint *d_kps, int nfr
     hipLaunchKernelGGL(sift::k_select_top, dim3(nframes), dim3(sift::SEL_THREADS), 0, s, (const sift::kp_t *)d_kps,
                        c->max_kp, nfinal, (sift::kp_t *)d_final, d_index, d_nvalid, d_desc, d_final_desc);
     HIP_TRY(hipGetLastError());
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_match_dev(sift_hip_ctx *c, const uint32_t *d_query, int nquery, const uint32_t *d_train, int ntrain, int npairs,
+                       sift_dmatch *d_matches, void *stream)
+{
+    if (int r = check_ctx(c)) return r;
+    if (nquery < 0 || ntrain < 0 || nquery > 32767 || ntrain > 32767)
+        return fail(SIFT_HIP_EINVAL, "nquery and ntrain must lie in [0, 32767] (DMatch_t holds 16-bit indices)");
+    if (npairs < 1) return fail(SIFT_HIP_EINVAL, "npairs must be >= 1");
+    if (nquery == 0) return SIFT_HIP_OK;
+    if (!d_query || !d_matches || (ntrain > 0 && !d_train)) return fail(SIFT_HIP_EINVAL, "null buffer");
+    if (((uintptr_t)d_query | (uintptr_t)d_train) & 15) return fail(SIFT_HIP_EINVAL, "descriptor arrays must be 16-byte aligned");
+    DevGuard g(c->device);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    dim3 grid((nquery + sift::MATCH_QUERIES - 1) / sift::MATCH_QUERIES, npairs);
+    hipLaunchKernelGGL(sift::k_match, grid, dim3(64 * sift::MATCH_WAVES), 0, s, d_query, nquery, d_train, ntrain,
+                       (sift::dmatch_t *)d_matches);
+    HIP_TRY(hipGetLastError());
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_match(sift_hip_ctx *c, const uint32_t *query, int nquery, const uint32_t *train, int ntrain, sift_dmatch *matches)
+{
+    if (int r = check_ctx(c)) return r;
+    if (nquery < 0 || ntrain < 0 || nquery > 32767 || ntrain > 32767)
+        return fail(SIFT_HIP_EINVAL, "nquery and ntrain must lie in [0, 32767] (DMatch_t holds 16-bit indices)");
+    if (nquery == 0) return SIFT_HIP_OK;
+    if (!query || !matches || (ntrain > 0 && !train)) return fail(SIFT_HIP_EINVAL, "null buffer");
+    DevGuard g(c->device);
+    hipStream_t s = c->stream;
+    // staging: both descriptor sets and the matches (grown on demand; at most 2 x 32767 rows)
+    const size_t qb = (size_t)nquery * 288, tb = (size_t)ntrain * 288, mb = (size_t)nquery * sizeof(sift_dmatch);
+    const size_t need = ((qb + 255) & ~(size_t)255) + ((tb + 255) & ~(size_t)255) + mb;
+    if (c->match_cap < need) {
+        if (c->d_match) (void)hipFree(c->d_match);
+        c->d_match = nullptr; c->match_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_match, need));
+        c->match_cap = need;
+    }
+    uint8_t *d_q = c->d_match, *d_t = d_q + ((qb + 255) & ~(size_t)255), *d_m = d_t + ((tb + 255) & ~(size_t)255);
+    HIP_TRY(hipMemcpyAsync(d_q, query, qb, hipMemcpyHostToDevice, s));
+    if (tb) HIP_TRY(hipMemcpyAsync(d_t, train, tb, hipMemcpyHostToDevice, s));
+    if (int r = sift_hip_match_dev(c, (const uint32_t *)d_q, nquery, (const uint32_t *)d_t, ntrain, 1, (sift_dmatch *)d_m, s)) return r;
+    HIP_TRY(hipMemcpyAsync(matches, d_m, mb, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return SIFT_HIP_OK;
 }
 

@@ -15,7 +15,7 @@ namespace {
 
 std::mutex g_mu;
 sift_hip_ctx *g_ctx = nullptr;
-int g_w = WIDTH, g_h = HEIGHT, g_dev = 0;
+int g_w = WIDTH, g_h = HEIGHT, g_dev = 0, g_geo = SIFT_HIP_GEOMETRY_CAM0;
 
 [[noreturn]] void die(const char *what)
 {
@@ -26,14 +26,14 @@ int g_w = WIDTH, g_h = HEIGHT, g_dev = 0;
 sift_hip_ctx *ctx()
 {
     if (!g_ctx) {
-        if (sift_hip_create(&g_ctx, g_dev, g_w, g_h, MAX_KEYPOINTS, 1) != SIFT_HIP_OK) die("sift_hip_create");
+        if (sift_hip_create_geometry(&g_ctx, g_dev, g_w, g_h, MAX_KEYPOINTS, 1, g_geo) != SIFT_HIP_OK) die("sift_hip_create");
         static bool registered = false;              // once per process, however often the context is recreated
         if (!registered) { atexit(sift_shutdown); registered = true; }
     }
     return g_ctx;
 }
 
-static_assert(sizeof(Keypoint_t) == sizeof(sift_keypoint) && sizeof(Grad_t) == sizeof(sift_grad), "C ABI layouts");
+static_assert(sizeof(Keypoint_t) == sizeof(sift_keypoint) && sizeof(Grad_t) == sizeof(sift_grad) && sizeof(DMatch_t) == sizeof(sift_dmatch), "C ABI layouts");
 
 }  // namespace
 
@@ -52,6 +52,15 @@ void sift_set_device(int device)
     if (device != g_dev) {
         if (g_ctx) { sift_hip_destroy(g_ctx); g_ctx = nullptr; }
         g_dev = device;
+    }
+}
+
+void sift_set_geometry(int geometry)
+{
+    std::lock_guard<std::mutex> l(g_mu);
+    if (geometry != g_geo) {
+        if (g_ctx) { sift_hip_destroy(g_ctx); g_ctx = nullptr; }
+        g_geo = geometry;
     }
 }
 
@@ -108,4 +117,10 @@ void compute_descriptor(Grad_t *pGrad, Keypoint_t *pKeypoint, uint8_t *pMainOrie
     if (sift_hip_descriptor(ctx(), (const sift_grad *)pGrad, (const sift_keypoint *)pKeypoint, pMainOrientation,
                             pDescriptorOut) != SIFT_HIP_OK)
         die("compute_descriptor");
+}
+
+void sift_match(const Desc_t *pQueryDesc, int nQuery, const Desc_t *pTrainDesc, int nTrain, DMatch_t *pMatches)
+{
+    std::lock_guard<std::mutex> l(g_mu);
+    if (sift_hip_match(ctx(), pQueryDesc, nQuery, pTrainDesc, nTrain, (sift_dmatch *)pMatches) != SIFT_HIP_OK) die("sift_match");
 }

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import (DESC_SIZE, GRAD_DTYPE, KP_DTYPE, MAX_FINAL_KEYPOINTS, MAX_KEYPOINTS, NSTAGES, check,
+from .capi import (DESC_SIZE, DMATCH_DTYPE, GRAD_DTYPE, KP_DTYPE, MAX_FINAL_KEYPOINTS, MAX_KEYPOINTS, NSTAGES, check,
                    load_library)
 
 
@@ -136,6 +136,18 @@ class SiftContext:
         nvalid = C.c_uint32(0)
         check(self._lib.sift_hip_select_top(self._h, _vp(kps), int(nfinal), _vp(final), _vp(index), C.byref(nvalid)))
         return final, index, int(nvalid.value)
+
+    def match(self, query_desc, train_desc):
+        """DMatch_t[nquery] of the nearest train row in the L1 sense (the reference has the type only)"""
+        q = np.ascontiguousarray(query_desc, np.uint32).reshape(-1, DESC_SIZE)
+        t = np.ascontiguousarray(train_desc, np.uint32).reshape(-1, DESC_SIZE)
+        m = np.empty(len(q), DMATCH_DTYPE)
+        check(self._lib.sift_hip_match(self._h, _vp(q), len(q), _vp(t), len(t), _vp(m)))
+        return m
+
+    def match_dev(self, d_query, nquery, d_train, ntrain, npairs, d_matches, stream=None):
+        check(self._lib.sift_hip_match_dev(self._h, _dp(d_query), int(nquery), _dp(d_train), int(ntrain), int(npairs),
+                                           _dp(d_matches), _dp(stream)))
 
     # -- device-buffer entry points (pointers into this device's memory) -----------
     def select_top_dev(self, d_kps, nframes, nfinal, d_final, d_index=None, d_nvalid=None, d_desc=None,
