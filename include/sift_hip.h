@@ -19,8 +19,13 @@
  *     stream per context (the *_dev calls take a stream argument; two calls of one
  *     context on two streams race), or two contexts for two streams.
  *   - frame size is a run-time parameter of the context (the reference fixes
- *     WIDTH/HEIGHT at compile time, SIFTParameters.hpp:17-18).  width must be a
- *     multiple of 4; width >= 4, height >= 1.
+ *     WIDTH/HEIGHT at compile time, SIFTParameters.hpp:17-18): any width in
+ *     [1, 65532] and height in [1, 65535].  Frames, Grad_t planes and every
+ *     other caller-side array are dense rows of `width` elements; internally rows
+ *     are padded to a multiple of 4 with columns that read as "outside the image".
+ *     (Widths that are multiples of 4 are taken as they are; others cost one
+ *     repacking pass per call, and their stand-alone orientation / descriptor
+ *     calls run the slower Grad_t sweep.)
  *   - outputs are always fully written: exactly max_keypoints keypoint slots
  *     (zero padded, DetectKeypoints.cpp:428-436) and max_keypoints*72
  *     descriptor words per frame.  Descriptors of padding slots are 0 (the
@@ -163,7 +168,7 @@ int sift_hip_match(sift_hip_ctx *ctx, const uint32_t *query_desc, int nquery, co
 
 /* The ingest step of main.cpp:51-58 for colour frames: 24-bit BGR rows (as in a BMP: `pitch` bytes
  * apart, a multiple of 4, 0 = 3*width; bottom_up != 0 when the first stored row is the bottom one)
- * to the width*height gray bytes the entry points above take, with the fixed-point weights of
+ * to the width*height gray bytes the entry points above take (pitch 0 = 3*width rounded up to 4), with the fixed-point weights of
  * cv::imread(..., CV_LOAD_IMAGE_GRAYSCALE): gray = (1868 B + 9617 G + 4899 R + 8192) >> 14.
  * OpenCV is not part of the reference tree: the formula is restated from its published source. */
 int sift_hip_gray_from_bgr(sift_hip_ctx *ctx, const uint8_t *bgr, long pitch, int bottom_up, uint8_t *gray);

@@ -265,9 +265,11 @@ __device__ __forceinline__ uint32_t pack4_q15(const uint64_t (&a)[2])
 // grid: x = ceil(W/4 / blockDim) blocks, y = strips, z = frames.
 // GUARD: skip slot groups whose rows lie outside the strip (short strips: small batches).  Without
 // it every slot is updated in every iteration, through the symmetric scheme above (long strips).
+// W is the row pitch of the frames, a multiple of 4; Wl <= W the logical width: columns Wl .. W-1 hold zeros
+// on input and get zeros in G1..G3 (to every later stage they are "outside the image").
 template <bool GUARD>
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, uint4 *__restrict__ pyr,
-                                              int W, int H, int rows)
+                                              int W, int H, int rows, int Wl)
 {
     const int W4 = W >> 2;
     const int xq = blockIdx.x * blockDim.x + threadIdx.x;
@@ -277,6 +279,8 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, 
     const size_t fofs = (size_t)blockIdx.z * (size_t)W * (size_t)H;
     const uint32_t *__restrict__ img = reinterpret_cast<const uint32_t *>(imgs + fofs);
     uint4 *__restrict__ out = pyr + (fofs >> 2);
+    const int inside = Wl - 4 * xq;                  // pixels of this group inside the logical width
+    const uint32_t gmask = inside >= 4 ? ~0u : inside <= 0 ? 0u : (1u << (8 * inside)) - 1u;
 
     // A row is read through a buffer descriptor of exactly its W bytes (none for rows outside the
     // image): the dwords left and right of the row (offsets below 0 wrap to 4 GB) and whole rows
@@ -357,9 +361,9 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ imgs, 
         if (y3 >= ys) {                       // y3 < ye holds by the loop bound
             uint4 o;
             o.x = sp;
-            o.y = d1[6];
-            o.z = d2[3];
-            o.w = pack4_q15(a3[0]);
+            o.y = d1[6] & gmask;
+            o.z = d2[3] & gmask;
+            o.w = pack4_q15(a3[0]) & gmask;
             out[(size_t)y3 * W4 + xq] = o;
         }
 #pragma unroll

@@ -187,7 +187,7 @@ __device__ __forceinline__ uint32_t finished_row(const BlurState<WHICH> &st)
 // A frame's units are (strip, block of 16 pixels) pairs, strip-major; unit group w is units 16 w .. 16 w + 15.
 template <int ROLE>
 __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs, uint4 *__restrict__ pyr, int W, int H, int rows,
-                                               int nstrips, int group, int lane)
+                                               int nstrips, int group, int lane, int Wl)
 {
     constexpr int AHEAD = BLUR_MFMA_AHEAD;
     const int W4 = W >> 2, NB = (W + 15) >> 4;
@@ -210,6 +210,9 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
     // the lane's own four pixels (group q of the row): source dword and the store
     const int q = 4 * xb + g;
     const bool qok = uvalid && q < W4;
+    // W is the row pitch (a multiple of 4), Wl <= W the logical width: G1..G3 of columns Wl .. W-1 are zeros
+    const int inside = Wl - 4 * q;
+    const uint32_t gmask = inside >= 4 ? ~0u : inside <= 0 ? 0u : (1u << (8 * inside)) - 1u;
 
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     auto request_row = [&](int y) -> u32x4 {                             // y differs between the lanes of a wave (strips)
@@ -252,7 +255,7 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
             slide_mfma<3>(s3, P);
             const int y3 = y - 9;                                        // G3 row y - 9 is finished
             const bool st_ok = qok && y3 >= ys && y3 < ye;
-            __builtin_amdgcn_raw_buffer_store_b32(finished_row<3>(s3), ws, st_ok ? (int)(((uint32_t)y3 * (uint32_t)W4 + (uint32_t)q) * 16u + 12u) : (int)OUTSIDE, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(finished_row<3>(s3) & gmask, ws, st_ok ? (int)(((uint32_t)y3 * (uint32_t)W4 + (uint32_t)q) * 16u + 12u) : (int)OUTSIDE, 0, 0);
         };
         for (int i = 0; i < n; i += AHEAD)
             static_for<0, AHEAD>([&](auto slot) { body(i + decltype(slot)::value, slot); });
@@ -293,7 +296,7 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
             const int y5 = y - 5;                                        // G2 row y - 5 and G1 row y - 2 are finished
             const bool st_ok = qok && y5 >= ys && y5 < ye;
             typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
-            __builtin_amdgcn_raw_buffer_store_b96(u32x3{sp, d1[2], finished_row<2>(s2)}, ws,
+            __builtin_amdgcn_raw_buffer_store_b96(u32x3{sp, d1[2] & gmask, finished_row<2>(s2) & gmask}, ws,
                                                   st_ok ? (int)(((uint32_t)y5 * (uint32_t)W4 + (uint32_t)q) * 16u) : (int)OUTSIDE, 0, 0);
             d1[2] = d1[1];
             d1[1] = d1[0];
@@ -305,14 +308,14 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
 }
 
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_blur_mfma(const uint8_t *__restrict__ imgs, uint4 *__restrict__ pyr, int W, int H, int rows, int nstrips)
+void k_blur_mfma(const uint8_t *__restrict__ imgs, uint4 *__restrict__ pyr, int W, int H, int rows, int nstrips, int Wl)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;          // waves 0-3: role 0, waves 4-7: role 1 (one of each per SIMD)
     const int group = blockIdx.x * 4 + (wave & 3);
     const int NB = (W + 15) >> 4;
     if (group * 16 >= NB * nstrips) return;                              // wave-uniform
-    if (wave < 4) blur_mfma_role<0>(imgs, pyr, W, H, rows, nstrips, group, lane);
-    else blur_mfma_role<1>(imgs, pyr, W, H, rows, nstrips, group, lane);
+    if (wave < 4) blur_mfma_role<0>(imgs, pyr, W, H, rows, nstrips, group, lane, Wl);
+    else blur_mfma_role<1>(imgs, pyr, W, H, rows, nstrips, group, lane, Wl);
 }
 
 }  // namespace sift

@@ -51,7 +51,7 @@ __device__ __forceinline__ u64 border_mask(int y, int seg, int W, int H)
 __global__ __launch_bounds__(256) void k_cull(const u64 *__restrict__ candmask, const uint32_t *__restrict__ keyplane,
                                               const uint32_t *__restrict__ list,
                                               const uint32_t *__restrict__ listcount, u64 *__restrict__ survmask,
-                                              uint32_t *__restrict__ rowcount, int W, int H, int S, int list_cap)
+                                              uint32_t *__restrict__ rowcount, int W, int H, int S, int list_cap, int Wl)
 {
     const int frame = blockIdx.y;
     const size_t fpix = (size_t)frame * (size_t)W * (size_t)H;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_cull(const u64 *__restrict__ candmask, 
         if (best) {
             const u64 bit = 1ull << (x & 63);
             atomicOr(survmask + (frow + y) * S + (x >> 6), bit);
-            if (border_mask(y, x >> 6, W, H) & bit) atomicAdd(rowcount + frow + y, 1u);
+            if (border_mask(y, x >> 6, Wl, H) & bit) atomicAdd(rowcount + frow + y, 1u);   // the border rule counts from the logical width
         }
     }
 }
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_emit(const u64 *__restrict__ survmask,
                                               const uint32_t *__restrict__ keyplane,
                                               const uint32_t *__restrict__ rowcount, kp_t *__restrict__ kps,
                                               uint32_t *__restrict__ total_ctx, uint32_t *__restrict__ total_out,
-                                              int W, int H, int S, int max_kp)
+                                              int W, int H, int S, int max_kp, int Wl)
 {
     __shared__ uint32_t part[4];
     const int y0 = blockIdx.x * 4, wave = threadIdx.x >> 6;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_emit(const u64 *__restrict__ survmask,
     for (int s0 = 0; s0 < S; s0 += 64) {
         const int seg = s0 + lane;
         u64 m = 0ull;
-        if (seg < S) m = (s0 == 0 ? m0 : survmask[(frow + y) * S + seg]) & border_mask(y, seg, W, H);
+        if (seg < S) m = (s0 == 0 ? m0 : survmask[(frow + y) * S + seg]) & border_mask(y, seg, Wl, H);
         const uint32_t n = (uint32_t)__popcll(m);
         // inclusive wave scan of n
         uint32_t inc = n;
@@ -184,14 +184,15 @@ __global__ __launch_bounds__(256) void k_emit(const u64 *__restrict__ survmask,
 // Debug: expand masks + keys to dense maps (sift_hip_debug_planes).
 __global__ void k_expand_maps(const u64 *__restrict__ candmask, const u64 *__restrict__ survmask,
                               const uint32_t *__restrict__ keyplane, uint16_t *__restrict__ cand,
-                              int32_t *__restrict__ eratio, uint16_t *__restrict__ surv, int W, int H, int S)
+                              int32_t *__restrict__ eratio, uint16_t *__restrict__ surv, int W, int H, int S, int Wl)
 {
+    // W: pitch of the key plane; Wl: logical width = pitch of the dense maps written here
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= W || y >= H) return;
-    const size_t i = (size_t)y * W + x;
+    if (x >= Wl || y >= H) return;
+    const size_t i = (size_t)y * Wl + x;
     const bool c = (candmask[(size_t)y * S + (x >> 6)] >> (x & 63)) & 1ull;
     const bool s = (survmask[(size_t)y * S + (x >> 6)] >> (x & 63)) & 1ull;
-    const uint32_t key = c ? keyplane[i] : 0u;
+    const uint32_t key = c ? keyplane[(size_t)y * W + x] : 0u;
     if (cand) cand[i] = c ? (uint16_t)(key & 0xffu) : 0;
     if (eratio) eratio[i] = c ? (int32_t)(key >> 8) : 0x7fffffff;
     if (surv) surv[i] = s ? (uint16_t)(key & 0xffu) : 0;

@@ -129,15 +129,19 @@ __global__ __launch_bounds__(256) void k_grad_pairs(const uint4 *__restrict__ gr
 // grid: x = max_kp keypoints, y = frames; block = 64 (one wave)
 // NA, NU, NB > 0: the quad table has exactly NA, NU and NB steps of 64 quads (the reference's masks:
 // 5, 9 and 2) and the sweep is straight-line code with every load of the window in flight at once
-template <int GFMT, int MODE, bool LOOP = false, int NA = 0, int NU = 0, int NB = 0>
+// SPEC: the geometry has orientation corrections (spec, nspec); the reference's geometry has none, and its
+// kernels carry no code for them (with it the straight-line variant no longer fits its 80 registers)
+template <int GFMT, int MODE, bool LOOP = false, int NA = 0, int NU = 0, int NB = 0, bool SPEC = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_describe(const void *__restrict__ gradv, const kp_t *__restrict__ kps,
                                                  const uint8_t *__restrict__ ori_in, uint8_t *__restrict__ ori_out,
                                                  uint32_t *__restrict__ desc, const uint2 *__restrict__ tab,
                                                  int n2, int n2pad, int ntab, const void *__restrict__ qtab,
                                                  int qa, int qu, int qb, const uint32_t *__restrict__ total, int W, int H,
                                                  int max_kp, const uint32_t *__restrict__ gate, uint32_t gate_want,
-                                                 int radius, int qrow4, const uint2 *__restrict__ spec, int nspec)
+                                                 int radius, int qrow4, const uint2 *__restrict__ spec, int nspec, int Wl)
 {
+    // W: row pitch of the internal gradient plane (a multiple of 4).  Wl <= W: the logical frame width, which is
+    // the pitch of the reference's linear addressing (pGrad[y*WIDTH + x ...]) and of a caller's Grad_t plane.
     // stand-alone calls launch this kernel once per gradient format; k_grad_pairs' flag says which runs
     if (gate && (*gate & 1u) != gate_want) return;
     constexpr bool PACK = GFMT == GRAD_PACKED16;
@@ -195,15 +199,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         uint4 *z = reinterpret_cast<uint4 *>(&hist[0][0]);
 #pragma unroll
         for (int i = 0; i < LROWS * 32 / 4 / 64; i++) z[i * 64 + lane] = make_uint4(0, 0, 0, 0);
-        if (nspec && lane < 8) corr[lane] = 0u;
+        if (SPEC && lane < 8) corr[lane] = 0u;
     }
     __syncthreads();
 
-    const long npix = (long)W * H;
-    const long origin = (long)(py - radius) * W + (px - radius);
+    const long npix = (long)Wl * H;
+    const long origin = (long)(py - radius) * Wl + (px - radius);
     const int W4 = W >> 2;
     const char *__restrict__ gplane = reinterpret_cast<const char *>(gradv) +
-                                      (size_t)blockIdx.y * (PACK ? gradp_frame_words(W, H) * 2 : (size_t)npix * 4);
+                                      (size_t)blockIdx.y * (PACK ? gradp_frame_words(W, H) * 2 : (size_t)npix * 4);   // Grad_t planes: logical pitch
     const uint32_t col4 = (uint32_t)(lane & 31) * 4u;
     char *const hbase = reinterpret_cast<char *>(&hist[0][0]);
 
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             idx = ok ? idx : 0;
             uint32_t g;
             if constexpr (PACK) {
-                const uint32_t y = (uint32_t)idx / (uint32_t)W, x = (uint32_t)idx - y * (uint32_t)W;
+                const uint32_t y = (uint32_t)idx / (uint32_t)Wl, x = (uint32_t)idx - y * (uint32_t)Wl;
                 const uint32_t pair = *reinterpret_cast<const uint32_t *>(gplane + gradp_quad_word((int)y, (int)(x >> 2), W4) * 2 + (x & 2u) * 2u);
                 g = gradp_unpack(pair, x & 1u);
             } else {
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         // quad sweep: the 19 aligned quads per row that cover the window must lie in their rows
         const int x0 = px - radius, y0 = py - radius;
         const int xph = x0 & 3, yph = y0 & 3;        // one table per alignment of the window in the plane
-        if (qtab && x0 - xph >= 0 && x0 - xph + qrow4 <= W && y0 >= 0 && py + radius < H) {
+        if (qtab && x0 - xph >= 0 && x0 - xph + qrow4 <= W && px + radius < Wl && y0 >= 0 && py + radius < H) {
             const char *gq = gplane + gradp_quad_word(y0 - yph, (x0 - xph) >> 2, W4) * 2;
             const char *tq = reinterpret_cast<const char *>(qtab) + (size_t)(yph * 4 + xph) * ((size_t)qa * 8u + (size_t)qu * 2u + (size_t)qb * 4u);
             if constexpr (NA + NU + NB > 0) quad_static(gq, tq);
@@ -432,14 +436,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             sweep(std::true_type{});
         }
     } else {
-        const bool inside = origin >= 0 && origin + 2L * radius * W + 2 * radius < npix;
+        const bool inside = origin >= 0 && origin + 2L * radius * Wl + 2 * radius < npix;
         if (inside) sweep(std::false_type{});
         else sweep(std::true_type{});
     }
     // Orientation corrections (none for the reference's geometry): the few pixels whose weight in the
     // orientation sum is not "once per union pixel" -- union pixels in the column the 2 * radius loop bound
     // (:70) leaves out count -1, pixels of the orientation mask outside the union +1 -- one lane each.
-    if (MODE != DESC_GIVEN_ORI && nspec) {
+    if constexpr (SPEC && MODE != DESC_GIVEN_ORI) {
         if (lane < nspec) {
             const uint2 e = spec[lane];
             const uint32_t g = gather(std::true_type{}, e.x, true);
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         uint32_t v = 0u - fin[72 + a];
 #pragma unroll
         for (int n = 0; n < 9; n++) v += fin[n * 8 + a];
-        if (nspec) v += corr[a];
+        if constexpr (SPEC) v += corr[a];
         // (int)v > 0 is the reference's test; the key orders by value, then by smaller a
         uint32_t key = ((int)v > 0) ? ((v << 3) | (uint32_t)(7 - a)) : 0u;
         // max over the 8 lanes of a group: lanes ^1 and ^2 by quad permutes; after those the two

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
                                                u64 *__restrict__ survmask, uint32_t *__restrict__ rowcount,
                                                uint32_t *__restrict__ list, uint32_t *__restrict__ listcount,
                                                uint16_t *__restrict__ gradp, uint32_t *__restrict__ gradfull,
-                                               int W, int H, int S, int contrastTh, int list_cap, int rows, int qcap)
+                                               int W, int H, int S, int contrastTh, int list_cap, int rows, int qcap, int Wl)
 {
     __shared__ uint32_t queue[DETECT_QUEUE];
     __shared__ u64 cmap[DETECT_ROWS * 4];             // candidate bits of the strip: row-major, 4 words per row
@@ -371,8 +371,17 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
                     gf[p] = 0;
                 }
             }
-            if constexpr (FULLGRAD)
-                *reinterpret_cast<uint4 *>(gradfull + fpix + (size_t)y * W + (size_t)g * 4) = make_uint4(gf[0], gf[1], gf[2], gf[3]);
+            if constexpr (FULLGRAD) {
+                // the caller's Grad_t plane has the logical width Wl as its pitch (W is the internal, padded one)
+                uint32_t *const gdst = gradfull + ((size_t)frame * H + (size_t)y) * (size_t)Wl + (size_t)g * 4;
+                if (Wl == W) {                                           // wave-uniform
+                    *reinterpret_cast<uint4 *>(gdst) = make_uint4(gf[0], gf[1], gf[2], gf[3]);
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 4; p++)
+                        if (g * 4 + p < Wl) gdst[p] = gf[p];
+                }
+            }
             uint2 o;
             o.x = gp[0] | gp[1];
             o.y = gp[2] | gp[3];

@@ -19,21 +19,46 @@ __device__ __forceinline__ uint32_t bgr_gray(uint32_t b, uint32_t g, uint32_t r)
     return (b * 1868u + g * 9617u + r * 4899u + 8192u) >> 14;
 }
 
-// grid: x = ceil(W/4 / 256), y = rows, z = frames; block = 256.  src: frames of `rows` x src_pitch
+// grid: x = ceil(ceil(W/4) / 256), y = rows, z = frames; block = 256.  src: frames of `rows` x src_pitch
 // bytes (pitch a multiple of 4, >= 3*W); flip: source row H-1-y feeds output row y (bottom-up files).
+// dst: gray rows of W bytes, any W (one dword store per lane when W is a multiple of 4, bytes otherwise).
 __global__ __launch_bounds__(256) void k_bgr2gray(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int W, int H,
                                                   long src_pitch, long src_frame, int flip)
 {
     const int xq = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (xq >= (W >> 2)) return;
+    if (4 * xq >= W) return;
     const int sy = flip ? H - 1 - y : y;
-    const uint32_t *__restrict__ p = reinterpret_cast<const uint32_t *>(src + (size_t)blockIdx.z * src_frame + (size_t)sy * src_pitch) + (size_t)xq * 3;
-    const uint32_t a = p[0], b = p[1], c = p[2];      // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
-    const uint32_t g0 = bgr_gray(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u);
-    const uint32_t g1 = bgr_gray(a >> 24, b & 255u, (b >> 8) & 255u);
-    const uint32_t g2 = bgr_gray((b >> 16) & 255u, b >> 24, c & 255u);
-    const uint32_t g3 = bgr_gray((c >> 8) & 255u, (c >> 16) & 255u, c >> 24);
-    reinterpret_cast<uint32_t *>(dst + ((size_t)blockIdx.z * H + y) * W)[xq] = g0 | g1 << 8 | g2 << 16 | g3 << 24;
+    const uint8_t *__restrict__ row = src + (size_t)blockIdx.z * src_frame + (size_t)sy * src_pitch;
+    uint8_t *__restrict__ out = dst + ((size_t)blockIdx.z * H + y) * W;
+    if (4 * xq + 4 <= W) {
+        const uint32_t *__restrict__ p = reinterpret_cast<const uint32_t *>(row) + (size_t)xq * 3;
+        const uint32_t a = p[0], b = p[1], c = p[2];      // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+        const uint32_t g0 = bgr_gray(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u);
+        const uint32_t g1 = bgr_gray(a >> 24, b & 255u, (b >> 8) & 255u);
+        const uint32_t g2 = bgr_gray((b >> 16) & 255u, b >> 24, c & 255u);
+        const uint32_t g3 = bgr_gray((c >> 8) & 255u, (c >> 16) & 255u, c >> 24);
+        if ((W & 3) == 0) {                               // block-uniform
+            reinterpret_cast<uint32_t *>(out)[xq] = g0 | g1 << 8 | g2 << 16 | g3 << 24;
+        } else {
+            out[4 * xq] = (uint8_t)g0; out[4 * xq + 1] = (uint8_t)g1; out[4 * xq + 2] = (uint8_t)g2; out[4 * xq + 3] = (uint8_t)g3;
+        }
+    } else {
+        for (int x = 4 * xq; x < W; x++) out[x] = (uint8_t)bgr_gray(row[3 * x], row[3 * x + 1], row[3 * x + 2]);
+    }
+}
+
+// Frames of any width into the internal layout: rows of `W` bytes (a multiple of 4), the columns from Wl on zero.
+// grid: x = ceil(W/4 / 256), y = rows, z = frames; block = 256
+__global__ __launch_bounds__(256) void k_pad_rows(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int Wl, int W, int H)
+{
+    const int xq = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (4 * xq >= W) return;
+    const uint8_t *__restrict__ row = src + ((size_t)blockIdx.z * H + y) * Wl;
+    uint32_t v = 0;
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+        if (4 * xq + p < Wl) v |= (uint32_t)row[4 * xq + p] << (8 * p);
+    reinterpret_cast<uint32_t *>(dst + ((size_t)blockIdx.z * H + y) * W)[xq] = v;
 }
 
 }  // namespace sift

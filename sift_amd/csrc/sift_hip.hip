@@ -243,8 +243,9 @@ QuadTable build_quad_table(int W, const Geometry &g)
 }  // namespace
 
 struct sift_hip_ctx {
-    int device = 0, W = 0, H = 0, S = 0, max_kp = 0, max_batch = 0;
-    size_t npix = 0;
+    int device = 0, W = 0, H = 0, S = 0, max_kp = 0, max_batch = 0;   // W: internal row pitch, a multiple of 4
+    int Wl = 0;                           // the caller's (logical) frame width; columns Wl .. W-1 of the internal planes are padding
+    size_t npix = 0;                      // W * H
     hipStream_t stream = nullptr;
     // persistent scratch, max_batch frames each
     uint8_t *d_img = nullptr;             // staging for host-buffer entry points
@@ -370,7 +371,24 @@ int pick_blur_mfma_rows(const sift_hip_ctx *c, int nframes)
     return best_rows;
 }
 
-// blur -> detect -> cull -> emit on device-resident frames
+// Frames of the caller's width into the internal pitch (columns Wl .. W-1 zero), or the caller's pointer itself
+// when the width is a multiple of 4 already.  `dst`: nframes * npix bytes of this context.
+const uint8_t *pad_frames(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint8_t *dst, hipStream_t s)
+{
+    if (c->Wl == c->W) return d_imgs;
+    dim3 grid((c->W / 4 + 255) / 256, c->H, nframes);
+    hipLaunchKernelGGL(sift::k_pad_rows, grid, dim3(256), 0, s, d_imgs, dst, c->Wl, c->W, c->H);
+    return dst;
+}
+
+// host frame -> internal staging (rows of W bytes; the padding columns were zeroed at create and are never written)
+hipError_t upload_frame(sift_hip_ctx *c, uint8_t *dst, const uint8_t *img, hipStream_t s)
+{
+    if (c->Wl == c->W) return hipMemcpyAsync(dst, img, c->npix, hipMemcpyHostToDevice, s);
+    return hipMemcpy2DAsync(dst, (size_t)c->W, img, (size_t)c->Wl, (size_t)c->Wl, (size_t)c->H, hipMemcpyHostToDevice, s);
+}
+
+// blur -> detect -> cull -> emit on device-resident frames in the internal pitch (pad_frames / upload_frame)
 int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_gradfull, sift::kp_t *d_kps,
                uint32_t *d_total, int th, hipStream_t s)
 {
@@ -383,7 +401,7 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
         const int rows = pick_blur_mfma_rows(c, nframes);
         const int nstrips = (H + rows - 1) / rows, NB = (W + 15) / 16;
         const int waves = (NB * nstrips + 15) / 16;
-        hipLaunchKernelGGL(sift::k_blur_mfma, dim3((waves + 3) / 4, nframes), dim3(512), 0, s, d_imgs, c->d_pyr, W, H, rows, nstrips);
+        hipLaunchKernelGGL(sift::k_blur_mfma, dim3((waves + 3) / 4, nframes), dim3(512), 0, s, d_imgs, c->d_pyr, W, H, rows, nstrips, c->Wl);
     } else {
         StageTimer t(c, ST_BLUR, s);
         const int rows = pick_blur_rows(c, nframes);
@@ -393,9 +411,9 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
         // long strips: the 18 warm-up rows are a small share, every slot is updated in every
         // iteration with the symmetric scheme; short strips skip the slots outside the strip
         if (rows >= c->blur_sym_rows)
-            hipLaunchKernelGGL(sift::k_blur<false>, grid, dim3(bs), 0, s, d_imgs, c->d_pyr, W, H, rows);
+            hipLaunchKernelGGL(sift::k_blur<false>, grid, dim3(bs), 0, s, d_imgs, c->d_pyr, W, H, rows, c->Wl);
         else
-            hipLaunchKernelGGL(sift::k_blur<true>, grid, dim3(bs), 0, s, d_imgs, c->d_pyr, W, H, rows);
+            hipLaunchKernelGGL(sift::k_blur<true>, grid, dim3(bs), 0, s, d_imgs, c->d_pyr, W, H, rows, c->Wl);
     }
     {
         StageTimer t(c, ST_DETECT, s);
@@ -412,11 +430,11 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
         if (d_gradfull)
             hipLaunchKernelGGL(sift::k_detect<true>, grid, dim3(64), 0, s, c->d_pyr, c->d_cand, c->d_key,
                                c->d_surv, c->d_rowcount, c->d_list, c->d_listcount, c->d_gradp, d_gradfull, W, H, S,
-                               th, c->list_cap, drows, c->detect_queue);
+                               th, c->list_cap, drows, c->detect_queue, c->Wl);
         else
             hipLaunchKernelGGL(sift::k_detect<false>, grid, dim3(64), 0, s, c->d_pyr, c->d_cand, c->d_key,
                                c->d_surv, c->d_rowcount, c->d_list, c->d_listcount, c->d_gradp,
-                               (uint32_t *)nullptr, W, H, S, th, c->list_cap, drows, c->detect_queue);
+                               (uint32_t *)nullptr, W, H, S, th, c->list_cap, drows, c->detect_queue, c->Wl);
     }
     {
         StageTimer t(c, ST_CULL, s);
@@ -424,13 +442,13 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
         const int blocks = (int)std::min<size_t>(1024, (c->npix / 128 + 255) / 256 + 1);
         dim3 grid(blocks, nframes);
         hipLaunchKernelGGL(sift::k_cull, grid, dim3(256), 0, s, c->d_cand, c->d_key, c->d_list, c->d_listcount,
-                           c->d_surv, c->d_rowcount, W, H, S, c->list_cap);
+                           c->d_surv, c->d_rowcount, W, H, S, c->list_cap, c->Wl);
     }
     {
         StageTimer t(c, ST_EMIT, s);
         dim3 grid((H + 1 + 3) / 4, nframes);
         hipLaunchKernelGGL(sift::k_emit, grid, dim3(256), 0, s, c->d_surv, c->d_key, c->d_rowcount, d_kps,
-                           c->d_total_ctx, d_total, W, H, S, c->max_kp);
+                           c->d_total_ctx, d_total, W, H, S, c->max_kp, c->Wl);
     }
     HIP_TRY(hipGetLastError());
     return SIFT_HIP_OK;
@@ -449,19 +467,30 @@ int run_describe(sift_hip_ctx *c, const void *d_grad, int nframes, const sift::k
     const int gx = std::max(1024, std::min(c->max_kp, (327680 + nframes - 1) / nframes));
     dim3 grid(gx >= c->max_kp ? c->max_kp : (gx & ~7), nframes);   // grouped slots: a multiple of 8 (one share per XCD)
     const uint32_t *tot = fused ? (const uint32_t *)c->d_total_ctx : (const uint32_t *)nullptr;
+    // geometries with orientation corrections (Cam1) run the table-driven variants with the correction step
+    if (c->nspec) {
+        if ((int)grid.x == c->max_kp)
+            hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false, 0, 0, 0, true>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
+                               d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec, c->Wl);
+        else
+            hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true, 0, 0, 0, true>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
+                               d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec, c->Wl);
+        HIP_TRY(hipGetLastError());
+        return SIFT_HIP_OK;
+    }
     // the reference's masks give 5 + 9 + 2 steps of 64 quads: straight-line variant
     if (GFMT == sift::GRAD_PACKED16 && (int)grid.x == c->max_kp && c->qa == 5 * 64 && c->qu == 9 * 64 && c->qb == 2 * 64)
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false, 5, 9, 2>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec, c->Wl);
     else if ((int)grid.x == c->max_kp)
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec, c->Wl);
     else if (GFMT == sift::GRAD_PACKED16 && c->qa == 5 * 64 && c->qu == 9 * 64 && c->qb == 2 * 64)
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true, 5, 9, 2>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec, c->Wl);
     else
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec, c->Wl);
     HIP_TRY(hipGetLastError());
     return SIFT_HIP_OK;
 }
@@ -476,6 +505,9 @@ int run_describe_planes(sift_hip_ctx *c, const sift_grad *d_grad, int nframes, c
 {
     StageTimer t(c, ST_DESCRIBE, s);
     HIP_TRY(hipMemsetAsync(c->d_gate, 0, 4, s));
+    // a caller's plane whose width is not a multiple of 4 is swept in its own format (its rows are not
+    // 16-byte aligned, which the conversion kernel reads them by)
+    if (c->Wl != c->W) return run_describe<sift::GRAD_FULL32, MODE>(c, d_grad, nframes, d_kps, ori_in, ori_out, d_desc, s);
     const dim3 grid((c->W / 4 + 255) / 256, (c->H + 3) / 4, nframes);
     hipLaunchKernelGGL(sift::k_grad_pairs, grid, dim3(256), 0, s, (const uint4 *)d_grad, c->d_gradp, c->d_gate, c->W, c->H);
     HIP_TRY(hipGetLastError());
@@ -518,6 +550,9 @@ int ensure_gradfull(sift_hip_ctx *c)
 
 }  // namespace
 
+static int fused_dev(sift_hip_ctx *c, const uint8_t *d_imgs, bool padded, int nframes, sift_keypoint *d_kps, uint32_t *d_desc,
+                     uint32_t *d_total, int contrastTh, void *stream);
+
 extern "C" {
 
 const char *sift_hip_last_error(void) { return g_err.c_str(); }
@@ -559,9 +594,11 @@ int sift_hip_create_geometry(sift_hip_ctx **out, int device, int width, int heig
     *out = nullptr;
     if (geometry != SIFT_HIP_GEOMETRY_CAM0 && geometry != SIFT_HIP_GEOMETRY_CAM1) return fail(SIFT_HIP_EINVAL, "unknown descriptor geometry");
     const Geometry &geo = kGeometry[geometry];
-    if (width < 4 || (width & 3) || height < 1 || width > 65532 || height > 65535)
-        return fail(SIFT_HIP_EINVAL, "width must be a multiple of 4 in [4,65532], height in [1,65535]");
+    if (width < 1 || height < 1 || width > 65532 || height > 65535)
+        return fail(SIFT_HIP_EINVAL, "width must lie in [1,65532], height in [1,65535]");
     if (max_keypoints < 1 || max_batch < 1) return fail(SIFT_HIP_EINVAL, "max_keypoints and max_batch must be >= 1");
+    const int logical_width = width;
+    width = (width + 3) & ~3;                        // internal row pitch; the extra columns are zeros = "outside the image"
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SIFT_HIP_ENODEV, "no HIP device");
     if (device < 0 || device >= ndev) return fail(SIFT_HIP_EINVAL, "device index out of range");
@@ -570,11 +607,13 @@ int sift_hip_create_geometry(sift_hip_ctx **out, int device, int width, int heig
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(SIFT_HIP_ENODEV, "device is not gfx950 (the library carries gfx950 code only)");
 
-    const WindowTable wt = build_window_table(width, geo);
+    // the pixel tables hold offsets of the reference's linear addressing (pitch = the logical width), the
+    // quad table byte offsets in the internal plane (pitch = the padded width)
+    const WindowTable wt = build_window_table(logical_width, geo);
     const std::vector<uint2> &tab = wt.e;
     if (tab.empty()) return fail(SIFT_HIP_EINVAL, "circle tables overlap three-fold");
     const QuadTable qt = build_quad_table(width, geo);
-    const std::vector<uint2> spec = build_special_table(width, geo);
+    const std::vector<uint2> spec = build_special_table(logical_width, geo);
     if (spec.size() > 64) return fail(SIFT_HIP_EINVAL, "more than 64 orientation corrections");
     // 16-bit bins of the describe kernel: a column's bin takes kmax pixels, and the reduction adds
     // 2 columns before widening (describe_kernel.h)
@@ -583,7 +622,7 @@ int sift_hip_create_geometry(sift_hip_ctx **out, int device, int width, int heig
 
     DevGuard g(device);
     sift_hip_ctx *c = new sift_hip_ctx;
-    c->device = device; c->W = width; c->H = height; c->S = (width + 63) / 64;
+    c->device = device; c->W = width; c->Wl = logical_width; c->H = height; c->S = (width + 63) / 64;
     c->max_kp = max_keypoints; c->max_batch = max_batch;
     c->npix = (size_t)width * height;
     const size_t B = (size_t)max_batch, np = c->npix, HS = (size_t)height * c->S;
@@ -591,6 +630,7 @@ int sift_hip_create_geometry(sift_hip_ctx **out, int device, int width, int heig
     auto A = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     A((void **)&c->d_img, B * np);
+    if (e == hipSuccess && logical_width != width) e = hipMemset(c->d_img, 0, B * np);   // the padding columns stay zero
     A((void **)&c->d_pyr, B * np * 4);
     c->list_cap = (int)std::min<size_t>(np / 2 + 64, 0x7fffffff);
     A((void **)&c->d_list, B * (size_t)c->list_cap * 4);
@@ -750,11 +790,21 @@ int sift_hip_detect_dev(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, sif
     DevGuard g(c->device);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     begin_call(c);
-    return run_detect(c, d_imgs, nframes, (uint32_t *)d_grad, (sift::kp_t *)d_kps, d_total, contrastTh, s);
+    return run_detect(c, pad_frames(c, d_imgs, nframes, c->d_img, s), nframes, (uint32_t *)d_grad, (sift::kp_t *)d_kps, d_total,
+                      contrastTh, s);
 }
 
 int sift_hip_detect_and_compute_dev(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, sift_keypoint *d_kps,
                                     uint32_t *d_desc, uint32_t *d_total, int contrastTh, void *stream)
+{
+    return fused_dev(c, d_imgs, false, nframes, d_kps, d_desc, d_total, contrastTh, stream);
+}
+
+}  // extern "C"
+
+// padded: d_imgs already has the internal pitch (the host-buffer entry points' staging)
+static int fused_dev(sift_hip_ctx *c, const uint8_t *d_imgs, bool padded, int nframes, sift_keypoint *d_kps, uint32_t *d_desc,
+                     uint32_t *d_total, int contrastTh, void *stream)
 {
     if (int r = check_ctx(c)) return r;
     if (!d_imgs || !d_kps || !d_desc) return fail(SIFT_HIP_EINVAL, "null buffer");
@@ -763,7 +813,8 @@ int sift_hip_detect_and_compute_dev(sift_hip_ctx *c, const uint8_t *d_imgs, int 
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     begin_call(c);
     auto enqueue = [&]() -> int {
-        if (int r = run_detect(c, d_imgs, nframes, nullptr, (sift::kp_t *)d_kps, d_total, contrastTh, s)) return r;
+        const uint8_t *src = padded ? d_imgs : pad_frames(c, d_imgs, nframes, c->d_img, s);
+        if (int r = run_detect(c, src, nframes, nullptr, (sift::kp_t *)d_kps, d_total, contrastTh, s)) return r;
         return run_describe<sift::GRAD_PACKED16, sift::DESC_FUSED>(c, c->d_gradp, nframes, (const sift::kp_t *)d_kps,
                                                                    nullptr, nullptr, d_desc, s);
     };
@@ -799,6 +850,8 @@ int sift_hip_detect_and_compute_dev(sift_hip_ctx *c, const uint8_t *d_imgs, int 
     HIP_TRY(hipGraphLaunch(c->gexec, s));
     return SIFT_HIP_OK;
 }
+
+extern "C" {
 
 int sift_hip_main_orientation_dev(sift_hip_ctx *c, const sift_grad *d_grad, int nframes, const sift_keypoint *d_kps,
                                   uint8_t *d_ori, void *stream)
@@ -895,13 +948,13 @@ int sift_hip_gray_from_bgr_dev(sift_hip_ctx *c, const uint8_t *d_bgr, int nframe
     if (int r = check_ctx(c)) return r;
     if (!d_bgr || !d_gray) return fail(SIFT_HIP_EINVAL, "null buffer");
     if (nframes < 1) return fail(SIFT_HIP_EINVAL, "nframes must be >= 1");
-    if (pitch == 0) pitch = 3L * c->W;
-    if (pitch < 3L * c->W || (pitch & 3)) return fail(SIFT_HIP_EINVAL, "pitch must be a multiple of 4 and >= 3 * width");
+    if (pitch == 0) pitch = (3L * c->Wl + 3) & ~3L;
+    if (pitch < 3L * c->Wl || (pitch & 3)) return fail(SIFT_HIP_EINVAL, "pitch must be a multiple of 4 and >= 3 * width");
     if ((uintptr_t)d_bgr & 3) return fail(SIFT_HIP_EINVAL, "d_bgr must be 4-byte aligned");
     DevGuard g(c->device);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    dim3 grid((c->W / 4 + 255) / 256, c->H, nframes);
-    hipLaunchKernelGGL(sift::k_bgr2gray, grid, dim3(256), 0, s, d_bgr, d_gray, c->W, c->H, pitch, pitch * c->H,
+    dim3 grid(((c->Wl + 3) / 4 + 255) / 256, c->H, nframes);
+    hipLaunchKernelGGL(sift::k_bgr2gray, grid, dim3(256), 0, s, d_bgr, d_gray, c->Wl, c->H, pitch, pitch * c->H,
                        bottom_up ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return SIFT_HIP_OK;
@@ -913,20 +966,21 @@ int sift_hip_gray_from_bgr(sift_hip_ctx *c, const uint8_t *bgr, long pitch, int 
 {
     if (int r = check_ctx(c)) return r;
     if (!bgr || !gray) return fail(SIFT_HIP_EINVAL, "null buffer");
-    if (pitch == 0) pitch = 3L * c->W;
-    if (pitch < 3L * c->W || (pitch & 3)) return fail(SIFT_HIP_EINVAL, "pitch must be a multiple of 4 and >= 3 * width");
+    if (pitch == 0) pitch = (3L * c->Wl + 3) & ~3L;
+    if (pitch < 3L * c->Wl || (pitch & 3)) return fail(SIFT_HIP_EINVAL, "pitch must be a multiple of 4 and >= 3 * width");
     DevGuard g(c->device);
     hipStream_t s = c->stream;
-    const size_t bytes = (size_t)pitch * c->H;
-    if (c->bgr_cap < bytes) {
+    // staging: the colour rows, then the gray frame (rows of the logical width)
+    const size_t bytes = (size_t)pitch * c->H, gbytes = (size_t)c->Wl * c->H;
+    if (c->bgr_cap < bytes + gbytes) {
         if (c->d_bgr) (void)hipFree(c->d_bgr);
         c->d_bgr = nullptr; c->bgr_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_bgr, bytes));
-        c->bgr_cap = bytes;
+        HIP_TRY(hipMalloc(&c->d_bgr, bytes + gbytes));
+        c->bgr_cap = bytes + gbytes;
     }
     HIP_TRY(hipMemcpyAsync(c->d_bgr, bgr, bytes, hipMemcpyHostToDevice, s));
-    if (int r = sift_hip_gray_from_bgr_dev(c, c->d_bgr, 1, pitch, bottom_up, c->d_img, s)) return r;
-    HIP_TRY(hipMemcpyAsync(gray, c->d_img, c->npix, hipMemcpyDeviceToHost, s));
+    if (int r = sift_hip_gray_from_bgr_dev(c, c->d_bgr, 1, pitch, bottom_up, c->d_bgr + bytes, s)) return r;
+    HIP_TRY(hipMemcpyAsync(gray, c->d_bgr + bytes, gbytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return SIFT_HIP_OK;
 }
@@ -958,10 +1012,8 @@ int sift_hip_detect_and_compute(sift_hip_ctx *c, const uint8_t *img, sift_keypoi
     if (!img || !kps || !desc) return fail(SIFT_HIP_EINVAL, "null buffer");
     DevGuard g(c->device);
     hipStream_t s = c->stream;
-    HIP_TRY(hipMemcpyAsync(c->d_img, img, c->npix, hipMemcpyHostToDevice, s));
-    if (int r = sift_hip_detect_and_compute_dev(c, c->d_img, 1, (sift_keypoint *)c->d_kps, c->d_desc, c->d_total,
-                                                contrastTh, s))
-        return r;
+    HIP_TRY(upload_frame(c, c->d_img, img, s));
+    if (int r = fused_dev(c, c->d_img, true, 1, (sift_keypoint *)c->d_kps, c->d_desc, c->d_total, contrastTh, s)) return r;
     HIP_TRY(hipMemcpyAsync(kps, c->d_kps, (size_t)c->max_kp * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(desc, c->d_desc, (size_t)c->max_kp * 72 * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -975,12 +1027,11 @@ int sift_hip_detect(sift_hip_ctx *c, const uint8_t *img, sift_grad *grad, sift_k
     DevGuard g(c->device);
     hipStream_t s = c->stream;
     if (grad) if (int r = ensure_gradfull(c)) return r;
-    HIP_TRY(hipMemcpyAsync(c->d_img, img, c->npix, hipMemcpyHostToDevice, s));
-    if (int r = sift_hip_detect_dev(c, c->d_img, 1, grad ? (sift_grad *)c->d_gradfull : nullptr,
-                                    (sift_keypoint *)c->d_kps, c->d_total, contrastTh, s))
-        return r;
+    HIP_TRY(upload_frame(c, c->d_img, img, s));
+    begin_call(c);
+    if (int r = run_detect(c, c->d_img, 1, grad ? c->d_gradfull : nullptr, c->d_kps, c->d_total, contrastTh, s)) return r;
     HIP_TRY(hipMemcpyAsync(kps, c->d_kps, (size_t)c->max_kp * 8, hipMemcpyDeviceToHost, s));
-    if (grad) HIP_TRY(hipMemcpyAsync(grad, c->d_gradfull, c->npix * 4, hipMemcpyDeviceToHost, s));
+    if (grad) HIP_TRY(hipMemcpyAsync(grad, c->d_gradfull, (size_t)c->Wl * c->H * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return SIFT_HIP_OK;
 }
@@ -992,7 +1043,7 @@ int sift_hip_main_orientation(sift_hip_ctx *c, const sift_grad *grad, const sift
     DevGuard g(c->device);
     hipStream_t s = c->stream;
     if (int r = ensure_gradfull(c)) return r;
-    HIP_TRY(hipMemcpyAsync(c->d_gradfull, grad, c->npix * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_gradfull, grad, (size_t)c->Wl * c->H * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->d_kps, kps, (size_t)c->max_kp * 8, hipMemcpyHostToDevice, s));
     if (int r = sift_hip_main_orientation_dev(c, (const sift_grad *)c->d_gradfull, 1, (const sift_keypoint *)c->d_kps,
                                               c->d_ori, s))
@@ -1009,7 +1060,7 @@ int sift_hip_descriptor(sift_hip_ctx *c, const sift_grad *grad, const sift_keypo
     DevGuard g(c->device);
     hipStream_t s = c->stream;
     if (int r = ensure_gradfull(c)) return r;
-    HIP_TRY(hipMemcpyAsync(c->d_gradfull, grad, c->npix * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_gradfull, grad, (size_t)c->Wl * c->H * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->d_kps, kps, (size_t)c->max_kp * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->d_ori, ori, (size_t)c->max_kp, hipMemcpyHostToDevice, s));
     if (int r = sift_hip_descriptor_dev(c, (const sift_grad *)c->d_gradfull, 1, (const sift_keypoint *)c->d_kps,
@@ -1099,14 +1150,13 @@ int batch_impl(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *imgs, 
             // H2D into buffer h once the kernels that last read it (chunk - nbuf) are done
             if (chunk >= (size_t)nbuf) step(hipStreamWaitEvent(s_in, k_done[h], 0), "wait");
             for (int k = 0; k < nb; k++)
-                step(hipMemcpyAsync(d_img + (size_t)k * np, imgs[mine[b0 + k]], np, hipMemcpyHostToDevice, s_in), "H2D frame");
+                step(upload_frame(c, d_img + (size_t)k * np, imgs[mine[b0 + k]], s_in), "H2D frame");
             step(hipEventRecord(in_done[h], s_in), "record");
             // kernels: after the frames have arrived and the previous outputs of buffer h have left
             step(hipStreamWaitEvent(s, in_done[h], 0), "wait");
             if (chunk >= (size_t)nbuf) step(hipStreamWaitEvent(s, out_done[h], 0), "wait");
             if (rc[ci] == SIFT_HIP_OK) {
-                int r = sift_hip_detect_and_compute_dev(c, d_img, nb, (sift_keypoint *)d_kps, d_desc, c->d_total + (size_t)h * half,
-                                                        contrastTh, s);
+                int r = fused_dev(c, d_img, true, nb, (sift_keypoint *)d_kps, d_desc, c->d_total + (size_t)h * half, contrastTh, s);
                 if (r) { rc[ci] = r; msg[ci] = g_err; }
                 if (!r && nfinal) {
                     r = sift_hip_select_top_dev(c, (sift_keypoint *)d_kps, nb, nfinal,
@@ -1288,7 +1338,7 @@ int sift_hip_detect_and_compute_static(int device, const uint8_t *d_imgs, int nf
         c->qa = qt.qa; c->qu = qt.qu; c->qb = qt.qb;
         st.table_width = width;
     }
-    c->W = width; c->H = height; c->S = (width + 63) / 64;
+    c->W = width; c->Wl = width; c->H = height; c->S = (width + 63) / 64;
     c->npix = (size_t)width * height;
     c->max_batch = nframes;
     c->list_cap = (int)std::min<size_t>(c->npix / 2 + 64, 0x7fffffff);
@@ -1318,32 +1368,34 @@ int sift_hip_debug_planes(sift_hip_ctx *c, int frame, uint8_t *g1, uint8_t *g2, 
     DevGuard g(c->device);
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipDeviceSynchronize());
-    const size_t np = c->npix;
+    const size_t np = c->npix, nl = (size_t)c->Wl * c->H;   // internal and caller-side plane sizes
     if (g1 || g2 || g3) {
         std::vector<uint32_t> pyr(np);    // per group of 4 pixels: src, G1, G2, G3 dwords
         HIP_TRY(hipMemcpy(pyr.data(), c->d_pyr + (size_t)frame * (np / 4), np * 4, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < np; i++) {
-            const size_t q = (i >> 2) * 4;
-            const int sh = (int)(i & 3) * 8;
-            if (g1) g1[i] = (uint8_t)(pyr[q + 1] >> sh);
-            if (g2) g2[i] = (uint8_t)(pyr[q + 2] >> sh);
-            if (g3) g3[i] = (uint8_t)(pyr[q + 3] >> sh);
-        }
+        for (int y = 0; y < c->H; y++)
+            for (int x = 0; x < c->Wl; x++) {
+                const size_t i = (size_t)y * c->W + x, o = (size_t)y * c->Wl + x;
+                const size_t q = (i >> 2) * 4;
+                const int sh = (int)(i & 3) * 8;
+                if (g1) g1[o] = (uint8_t)(pyr[q + 1] >> sh);
+                if (g2) g2[o] = (uint8_t)(pyr[q + 2] >> sh);
+                if (g3) g3[o] = (uint8_t)(pyr[q + 3] >> sh);
+            }
     }
     if (cand || eratio || surv) {
         uint16_t *d_c = nullptr, *d_s = nullptr;
         int32_t *d_e = nullptr;
-        HIP_TRY(hipMalloc(&d_c, np * 2));
-        HIP_TRY(hipMalloc(&d_s, np * 2));
-        HIP_TRY(hipMalloc(&d_e, np * 4));
+        HIP_TRY(hipMalloc(&d_c, nl * 2));
+        HIP_TRY(hipMalloc(&d_s, nl * 2));
+        HIP_TRY(hipMalloc(&d_e, nl * 4));
         const size_t HS = (size_t)c->H * c->S;
-        dim3 grid((c->W + 255) / 256, c->H);
+        dim3 grid((c->Wl + 255) / 256, c->H);
         hipLaunchKernelGGL(sift::k_expand_maps, grid, dim3(256), 0, c->stream, c->d_cand + frame * HS,
-                           c->d_surv + frame * HS, c->d_key + (size_t)frame * np, d_c, d_e, d_s, c->W, c->H, c->S);
+                           c->d_surv + frame * HS, c->d_key + (size_t)frame * np, d_c, d_e, d_s, c->W, c->H, c->S, c->Wl);
         hipError_t e = hipStreamSynchronize(c->stream);
-        if (e == hipSuccess && cand) e = hipMemcpy(cand, d_c, np * 2, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && surv) e = hipMemcpy(surv, d_s, np * 2, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && eratio) e = hipMemcpy(eratio, d_e, np * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && cand) e = hipMemcpy(cand, d_c, nl * 2, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && surv) e = hipMemcpy(surv, d_s, nl * 2, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && eratio) e = hipMemcpy(eratio, d_e, nl * 4, hipMemcpyDeviceToHost);
         hipFree(d_c); hipFree(d_s); hipFree(d_e);
         if (e != hipSuccess) return fail(SIFT_HIP_EHIP, "debug planes", e);
     }

@@ -50,8 +50,11 @@ def test_argument_errors_without_touching_a_device(sift):
     lib = sift.load_library()
     h = C.c_void_p()
     assert lib.sift_hip_create(None, 0, 640, 480, 10000, 1) == -1
-    assert lib.sift_hip_create(C.byref(h), 0, 642, 480, 10000, 1) == -1        # width % 4
-    assert b"multiple of 4" in lib.sift_hip_last_error()
+    assert lib.sift_hip_create(C.byref(h), 0, 0, 480, 10000, 1) == -1
+    assert b"width" in lib.sift_hip_last_error()
+    assert lib.sift_hip_create(C.byref(h), 0, 70000, 480, 10000, 1) == -1
+    assert lib.sift_hip_create_geometry(C.byref(h), 0, 640, 480, 10000, 1, 7) == -1
+    assert b"geometry" in lib.sift_hip_last_error()
     assert lib.sift_hip_create(C.byref(h), 0, 640, 0, 10000, 1) == -1
     assert lib.sift_hip_create(C.byref(h), 0, 640, 480, 0, 1) == -1
     assert lib.sift_hip_create(C.byref(h), 0, 640, 480, 10000, 0) == -1

@@ -31,7 +31,7 @@ def test_oracle_bgr2gray(orc):
 @pytest.mark.gpu
 def test_gpu_bgr2gray_equals_oracle(sift, orc):
     rng = np.random.default_rng(2)
-    for W, H, pad in ((64, 48, 0), (68, 5, 8), (1920, 1080, 0), (324, 7, 4)):
+    for W, H, pad in ((64, 48, 0), (68, 5, 8), (1920, 1080, 0), (324, 7, 4), (321, 9, 1), (5, 3, 1), (1601, 4, 5), (642, 3, 2)):
         pitch = 3 * W + pad
         buf = rng.integers(0, 256, (H, pitch), dtype=np.uint8)
         with sift.SiftContext(W, H) as ctx:

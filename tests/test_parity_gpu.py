@@ -664,3 +664,55 @@ def test_cam1_geometry(sift, orc):
             rk, rd, _ = orc.detect_and_compute(imgs[b], geometry=1)
             n = nvalid(rk)
             assert (kps[b] == rk).all() and (desc[b, :n] == rd[:n]).all() and not desc[b, n:].any(), b
+
+
+@pytest.mark.parametrize("W,H", [(643, 481), (1601, 300), (321, 240), (150, 149), (5, 3), (1, 1), (1923, 200)])
+def test_widths_that_are_not_multiples_of_four(sift, orc, W, H):
+    """WIDTH is an arbitrary macro in the reference (SIFTParameters.hpp:17).  Internally rows are padded to a
+    multiple of 4 with columns that read as outside the image; every caller-side array keeps the logical width
+    as its pitch.  All stages, the Grad_t plane, the stand-alone calls (with keypoints whose windows wrap over
+    the row end in the reference's linear addressing), both blur kernels and a batch on device buffers."""
+    import torch
+    img = orc.synth_frame(31, W, H)
+    check_full(sift, orc, img)
+    rk, rd, total = orc.detect_and_compute(img)
+    n = nvalid(rk)
+    with sift.SiftContext(W, H, max_batch=3) as ctx:
+        ctx.set_blur_mfma(False)
+        kps, desc = ctx.sift_detect_and_compute(img)
+        assert (kps == rk).all() and (desc[:n] == rd[:n]).all() and not desc[n:].any()
+        ctx.set_blur_mfma(True)
+        grad = orc.sift_detect(img)["grad"]
+        rng = np.random.default_rng(W)
+        ck = np.zeros(10000, sift.KP_DTYPE)
+        m = 400
+        ck["x"][:m] = rng.integers(0, W, m)
+        ck["y"][:m] = rng.integers(0, H, m)
+        ck["contrast"][:m] = 5
+        ro = orc.main_orientation(grad, ck)
+        assert (ctx.compute_main_orientation(grad, ck) == ro).all()
+        assert (ctx.compute_descriptor(grad, ck, ro) == orc.descriptor(grad, ck, ro)).all()
+        imgs = np.stack([img, orc.synth_frame(32, W, H), img])
+        d_img = torch.from_numpy(imgs).cuda()
+        d_kps = torch.full((3, 10000, 2), -1, dtype=torch.int32, device="cuda")
+        d_desc = torch.full((3, 10000, 72), -1, dtype=torch.int32, device="cuda")
+        d_grad = torch.full((3, H, W), -1, dtype=torch.int32, device="cuda")
+        d_kps2 = torch.zeros_like(d_kps)
+        ctx.detect_and_compute_dev(d_img, 3, d_kps, d_desc)
+        ctx.detect_dev(d_img, 3, d_grad, d_kps2)
+        ctx.sync()
+        assert torch.equal(d_kps, d_kps2)
+        k = d_kps.cpu().numpy().view(sift.KP_DTYPE).reshape(3, 10000)
+        d = d_desc.cpu().numpy().view(np.uint32)
+        g = d_grad.cpu().numpy().view(sift.GRAD_DTYPE).reshape(3, H, W)
+        for b in range(3):
+            bk, bd, _ = orc.detect_and_compute(imgs[b])
+            bn = nvalid(bk)
+            assert (k[b] == bk).all() and (d[b, :bn] == bd[:bn]).all() and not d[b, bn:].any()
+            bg = orc.sift_detect(imgs[b])["grad"]
+            assert (g[b]["ang"] == bg["ang"]).all() and (g[b]["mag"] == bg["mag"]).all()
+    if W >= 300:
+        from sift_amd.hw_sift import batch
+        with sift.SiftContext(W, H, max_batch=2) as ctx:
+            bk, bd = batch([ctx], [img, imgs[1], img])
+            assert (bk[0] == rk).all() and (bk[2] == rk).all() and (bd[2, :n] == rd[:n]).all()
