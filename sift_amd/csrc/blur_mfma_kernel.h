@@ -33,8 +33,8 @@
 //     fragments (132) of all three tables would leave one wave per SIMD with nothing to hide memory
 //     latency behind, so the work of a group of units is split over two waves: role 0 runs the 19x19
 //     table (30 MFMAs per row, 184 registers), role 1 the 11x11 and 5x5 tables (30 MFMAs, 188 registers).
-//     A workgroup is 4 + 4 such waves, so every SIMD holds one of each; role 0 stores the G3 dword of a
-//     group of four pixels, role 1 its {src, G1, G2} dwords (the L2 merges the two pieces of a line).
+//     A workgroup is 2 + 2 such waves and two workgroups fill a CU, two waves per SIMD; role 0 stores the
+//     G3 dword of a group of four pixels, role 1 its {src, G1, G2} dwords (the L2 merges the two pieces of a line).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -183,7 +183,7 @@ __device__ __forceinline__ uint32_t finished_row(const BlurState<WHICH> &st)
     return pack4_q15(t);
 }
 
-// grid: x = ceil(unit groups per frame / 4) blocks of 512 (4 unit groups x 2 roles), y = frames.
+// grid: x = ceil(unit groups per frame / g) blocks of 128 g threads (g unit groups x 2 roles), y = frames.
 // A frame's units are (strip, block of 16 pixels) pairs, strip-major; unit group w is units 16 w .. 16 w + 15.
 template <int ROLE>
 __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs, uint4 *__restrict__ pyr, int W, int H, int rows,
@@ -310,11 +310,13 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_blur_mfma(const uint8_t *__restrict__ imgs, uint4 *__restrict__ pyr, int W, int H, int rows, int nstrips, int Wl)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;          // waves 0-3: role 0, waves 4-7: role 1 (one of each per SIMD)
-    const int group = blockIdx.x * 4 + (wave & 3);
+    // a workgroup of 128 g threads takes g unit groups: its first g waves run role 0, the other g role 1
+    // (launched with g = 2: two workgroups per CU, every SIMD holds two waves)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = (int)blockDim.x >> 7;
+    const int group = blockIdx.x * half + (wave % half);
     const int NB = (W + 15) >> 4;
     if (group * 16 >= NB * nstrips) return;                              // wave-uniform
-    if (wave < 4) blur_mfma_role<0>(imgs, pyr, W, H, rows, nstrips, group, lane, Wl);
+    if (wave < half) blur_mfma_role<0>(imgs, pyr, W, H, rows, nstrips, group, lane, Wl);
     else blur_mfma_role<1>(imgs, pyr, W, H, rows, nstrips, group, lane, Wl);
 }
 

@@ -401,7 +401,9 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
         const int rows = pick_blur_mfma_rows(c, nframes);
         const int nstrips = (H + rows - 1) / rows, NB = (W + 15) / 16;
         const int waves = (NB * nstrips + 15) / 16;
-        hipLaunchKernelGGL(sift::k_blur_mfma, dim3((waves + 3) / 4, nframes), dim3(512), 0, s, d_imgs, c->d_pyr, W, H, rows, nstrips, c->Wl);
+        // workgroups of two unit groups (two waves of each role; two workgroups fill a CU's register file):
+        // measured against one and four groups per workgroup, 1.42 - 1.49 ms against 1.52 and 1.54 - 1.61 per 256 frames
+        hipLaunchKernelGGL(sift::k_blur_mfma, dim3((waves + 1) / 2, nframes), dim3(256), 0, s, d_imgs, c->d_pyr, W, H, rows, nstrips, c->Wl);
     } else {
         StageTimer t(c, ST_BLUR, s);
         const int rows = pick_blur_rows(c, nframes);

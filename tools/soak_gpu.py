@@ -26,7 +26,7 @@ def main():
     nk = 0
     for case in range(ncases):
         rng = np.random.default_rng(first + case)
-        W = int(rng.integers(37, 300)) * 4
+        W = int(rng.integers(148, 1200))                              # any width, multiples of 4 or not
         H = int(rng.integers(145, 700))
         kind = case % 4
         if kind == 3:
@@ -44,6 +44,12 @@ def main():
         th = int(rng.integers(1, 30))
         _, _, n, total = T.check_full(sift, orc, img, th=th)
         nk += n
+        if case % 3 == 0:                                             # the Cam1 geometry and the blur on the vector ALUs
+            rk, rd, _ = orc.detect_and_compute(img, th, geometry=1)
+            with sift.SiftContext(W, H, geometry=1) as ctx:
+                ctx.set_blur_mfma(False)
+                kps, desc = ctx.sift_detect_and_compute(img, th)
+            assert (kps == rk).all() and (desc[:n] == rd[:n]).all() and not desc[n:].any(), "Cam1 case %d" % case
         if case % 10 == 9:
             print("case %d ok (%dx%d th %d: %d keypoints), %.0f s" % (case, W, H, th, n, time.time() - t0), flush=True)
     print("soak ok: %d cases, %d keypoints compared" % (ncases, nk))
