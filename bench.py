@@ -165,7 +165,7 @@ def check_outputs(seeds, d_kps, d_desc, totals, expected, what):
     return len(seeds)
 
 
-def run_config(sift_amd, torch, dev, W, H, seeds, steps, warmup, th, spin_s=0.25, profile=True):
+def run_config(sift_amd, torch, dev, W, H, seeds, steps, warmup, th, spin_s=0.5, profile=True):
     """frames of `seeds` resident on GPU `dev`, a context, spin-up and warm-up steps done ->
     (context, the step function, (d_img, d_kps, d_desc, d_tot))"""
     from sift_amd.synth import synth_frames_torch
