@@ -1151,8 +1151,18 @@ int batch_impl(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *imgs, 
             uint32_t *d_desc = c->d_desc + (size_t)h * half * K * 72;
             // H2D into buffer h once the kernels that last read it (chunk - nbuf) are done
             if (chunk >= (size_t)nbuf) step(hipStreamWaitEvent(s_in, k_done[h], 0), "wait");
-            for (int k = 0; k < nb; k++)
-                step(upload_frame(c, d_img + (size_t)k * np, imgs[mine[b0 + k]], s_in), "H2D frame");
+            // frames that lie back to back in host memory travel as one copy (fewer, larger transfers)
+            const size_t host_frame = (size_t)c->Wl * c->H;
+            for (int k = 0; k < nb;) {
+                int run = 1;
+                if (c->Wl == c->W)
+                    while (k + run < nb && imgs[mine[b0 + k + run]] == imgs[mine[b0 + k]] + (size_t)run * host_frame) run++;
+                if (run > 1)
+                    step(hipMemcpyAsync(d_img + (size_t)k * np, imgs[mine[b0 + k]], (size_t)run * np, hipMemcpyHostToDevice, s_in), "H2D frames");
+                else
+                    step(upload_frame(c, d_img + (size_t)k * np, imgs[mine[b0 + k]], s_in), "H2D frame");
+                k += run;
+            }
             step(hipEventRecord(in_done[h], s_in), "record");
             // kernels: after the frames have arrived and the previous outputs of buffer h have left
             step(hipStreamWaitEvent(s, in_done[h], 0), "wait");
@@ -1171,7 +1181,22 @@ int batch_impl(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *imgs, 
             step(hipEventRecord(k_done[h], s), "record");
             // D2H
             step(hipStreamWaitEvent(s_out, k_done[h], 0), "wait");
-            for (int k = 0; k < nb && rc[ci] == SIFT_HIP_OK; k++) {
+            // with one context the chunk's frames are consecutive in the caller's arrays: one copy per array
+            const bool consecutive = nctx == 1;
+            if (consecutive && rc[ci] == SIFT_HIP_OK) {
+                const size_t f = (size_t)mine[b0], n = (size_t)nb;
+                if (!nfinal) {
+                    step(hipMemcpyAsync(kps + f * K, d_kps, n * K * 8, hipMemcpyDeviceToHost, s_out), "D2H keypoints");
+                    step(hipMemcpyAsync(desc + f * K * 72, d_desc, n * K * 72 * 4, hipMemcpyDeviceToHost, s_out), "D2H descriptors");
+                } else {
+                    const size_t NF = (size_t)nfinal, o = (size_t)h * half * NF;
+                    step(hipMemcpyAsync(final_kps + f * NF, c->d_tfinal + o, n * NF * 8, hipMemcpyDeviceToHost, s_out), "D2H final keypoints");
+                    if (final_index) step(hipMemcpyAsync(final_index + f * NF, c->d_tindex + o, n * NF * 4, hipMemcpyDeviceToHost, s_out), "D2H slots");
+                    if (final_desc) step(hipMemcpyAsync(final_desc + f * NF * 72, c->d_tdesc + o * 72, n * NF * 72 * 4, hipMemcpyDeviceToHost, s_out), "D2H descriptor rows");
+                    if (nvalid) step(hipMemcpyAsync(nvalid + f, c->d_tnvalid + (size_t)h * half, n * 4, hipMemcpyDeviceToHost, s_out), "D2H counts");
+                }
+            }
+            for (int k = 0; k < nb && rc[ci] == SIFT_HIP_OK && !consecutive; k++) {
                 const size_t f = (size_t)mine[b0 + k];
                 if (!nfinal) {
                     step(hipMemcpyAsync(kps + f * K, d_kps + (size_t)k * K, K * 8, hipMemcpyDeviceToHost, s_out), "D2H keypoints");
