@@ -98,44 +98,63 @@ __global__ __launch_bounds__(256) void k_cull(const u64 *__restrict__ candmask, 
     }
 }
 
+// Exclusive prefix of the row counts: rowbase[y] = keypoints in rows above y, rowbase[H] = the frame's total.
+// One block per frame; chunks of 1024 rows, block scan per chunk.
+// grid: x = frames; block = 1024
+__global__ __launch_bounds__(1024) void k_rowprefix(const uint32_t *__restrict__ rowcount, uint32_t *__restrict__ rowbase, int H)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t *__restrict__ rc = rowcount + (size_t)blockIdx.x * H;
+    uint32_t *__restrict__ rb = rowbase + (size_t)blockIdx.x * (H + 1);
+    if (threadIdx.x == 0) carry = 0u;
+    __syncthreads();
+    for (int y0 = 0; y0 <= H; y0 += 1024) {
+        const int y = y0 + (int)threadIdx.x;
+        const uint32_t n = y < H ? rc[y] : 0u;
+        uint32_t inc = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t before = carry;
+        for (int w = 0; w < wave; w++) before += wsum[w];
+        if (y <= H) rb[y] = before + inc - n;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + inc;
+        __syncthreads();
+    }
+}
+
 // One wave per image row (+ one extra wave per frame for padding / totals: total_ctx is the
 // context's own copy of the uncapped count, which the fused describe kernel reads; total_out the
-// caller's, optional).
+// caller's, optional).  rowbase: k_rowprefix's exclusive prefix of the row counts.
 // grid: x = ceil((H+1)/4) blocks of 256, y = frames.
 __global__ __launch_bounds__(256) void k_emit(const u64 *__restrict__ survmask,
                                               const uint32_t *__restrict__ keyplane,
-                                              const uint32_t *__restrict__ rowcount, kp_t *__restrict__ kps,
+                                              const uint32_t *__restrict__ rowbase, kp_t *__restrict__ kps,
                                               uint32_t *__restrict__ total_ctx, uint32_t *__restrict__ total_out,
                                               int W, int H, int S, int max_kp, int Wl)
 {
-    __shared__ uint32_t part[4];
-    const int y0 = blockIdx.x * 4, wave = threadIdx.x >> 6;
-    const int y = y0 + wave;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    if (y > H) return;
     const size_t frow = (size_t)blockIdx.y * H;
-    const uint32_t *__restrict__ rc = rowcount + frow;
+    const uint32_t *__restrict__ rb = rowbase + (size_t)blockIdx.y * (H + 1);
     kp_t *__restrict__ out = kps + (size_t)blockIdx.y * max_kp;
 
-    // the row's own count and its first 64 mask segments are requested together with the counts
-    // of the rows above, so that the wave waits for memory once before it reads the keys
-    uint32_t own = 0;
+    // keypoints in the rows above (k_rowprefix; y == H: the frame total) and, requested together with
+    // them, the row's first 64 mask segments, so that the wave waits for memory once before it reads the keys
+    uint32_t base = rb[y];
     u64 m0 = 0ull;
     if (y < H) {
-        own = rc[y];
         if (lane < S) m0 = survmask[(frow + y) * S + lane];
+        if (rb[y + 1] == base) return;               // nothing to emit from this row
     }
-    // keypoints in the rows above the block's four: summed once by the whole block
-    uint32_t base = 0;
-    for (int r = threadIdx.x; r < min(y0, H); r += 256) base += rc[r];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) base += __shfl_xor(base, o);
-    if (lane == 0) part[wave] = base;
-    __syncthreads();
-    if (y > H) return;
-    if (y < H && own == 0) return;                   // nothing to emit from this row
-    // keypoints in rows above (y == H: the frame total)
-    base = part[0] + part[1] + part[2] + part[3];
-    for (int r = y0; r < y; r++) base += rc[r];      // r < y <= H
 
     if (y == H) {
         // padding (:428-436) and the uncapped total (nKeypointsTotal, :405-406)

@@ -255,6 +255,7 @@ struct sift_hip_ctx {
     int list_cap = 0;
     uint32_t *d_key = nullptr;            // (E<<8)|contrast at candidates
     uint32_t *d_rowcount = nullptr;       // [H]
+    uint32_t *d_rowbase = nullptr;        // [H + 1] exclusive prefix of d_rowcount (k_rowprefix)
     uint16_t *d_gradp = nullptr;          // internal gradient plane (gradp_pack, detect_kernel.h)
     uint32_t *d_gradfull = nullptr;       // Grad_t staging (1 frame, lazily allocated)
     sift::kp_t *d_kps = nullptr;          // staging for host-buffer entry points
@@ -449,7 +450,8 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
     {
         StageTimer t(c, ST_EMIT, s);
         dim3 grid((H + 1 + 3) / 4, nframes);
-        hipLaunchKernelGGL(sift::k_emit, grid, dim3(256), 0, s, c->d_surv, c->d_key, c->d_rowcount, d_kps,
+        hipLaunchKernelGGL(sift::k_rowprefix, dim3(nframes), dim3(1024), 0, s, c->d_rowcount, c->d_rowbase, H);
+        hipLaunchKernelGGL(sift::k_emit, grid, dim3(256), 0, s, c->d_surv, c->d_key, c->d_rowbase, d_kps,
                            c->d_total_ctx, d_total, W, H, S, c->max_kp, c->Wl);
     }
     HIP_TRY(hipGetLastError());
@@ -641,6 +643,7 @@ int sift_hip_create_geometry(sift_hip_ctx **out, int device, int width, int heig
     A((void **)&c->d_surv, B * HS * 8);
     A((void **)&c->d_key, B * np * 4);
     A((void **)&c->d_rowcount, B * (size_t)height * 4);
+    A((void **)&c->d_rowbase, B * ((size_t)height + 1) * 4);
     A((void **)&c->d_gradp, B * sift::gradp_frame_words(width, height) * 2);
     A((void **)&c->d_kps, B * (size_t)max_keypoints * 8);
     A((void **)&c->d_desc, B * (size_t)max_keypoints * 72 * 4);
@@ -670,7 +673,7 @@ void sift_hip_destroy(sift_hip_ctx *c)
     if (!c) return;
     DevGuard g(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->d_img, c->d_pyr, c->d_list, c->d_listcount, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_gradp,
+    void *ptrs[] = {c->d_img, c->d_pyr, c->d_list, c->d_listcount, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_rowbase, c->d_gradp,
                     c->d_gradfull, c->d_final, c->d_findex, c->d_nvalid, c->d_tfinal, c->d_tindex, c->d_tdesc, c->d_tnvalid, c->d_bgr, c->d_match, c->d_kps, c->d_desc, c->d_total, c->d_total_ctx, c->d_ori, c->d_tab, c->d_qtab, c->d_gate, c->d_spec};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &ps : c->prof)
@@ -1276,7 +1279,7 @@ std::mutex g_static_mu;
 
 // the buffers of a call, carved out of the array behind the tables (256-byte aligned)
 struct StaticLayout {
-    size_t pyr, list, listcount, cand, surv, key, rowcount, gradp, total, end;
+    size_t pyr, list, listcount, cand, surv, key, rowcount, rowbase, gradp, total, end;
     StaticLayout(int W, int H, int nframes)
     {
         const size_t B = (size_t)nframes, np = (size_t)W * H, HS = (size_t)H * (size_t)((W + 63) / 64);
@@ -1289,6 +1292,7 @@ struct StaticLayout {
         surv = take(B * HS * 8);
         key = take(B * np * 4);
         rowcount = take(B * (size_t)H * 4);
+        rowbase = take(B * ((size_t)H + 1) * 4);
         gradp = take(B * sift::gradp_frame_words(W, H) * 2);
         total = take(B * 4);
         end = o;
@@ -1376,6 +1380,7 @@ int sift_hip_detect_and_compute_static(int device, const uint8_t *d_imgs, int nf
     c->d_surv = (unsigned long long *)(st.base + L.surv);
     c->d_key = (uint32_t *)(st.base + L.key);
     c->d_rowcount = (uint32_t *)(st.base + L.rowcount);
+    c->d_rowbase = (uint32_t *)(st.base + L.rowbase);
     c->d_gradp = (uint16_t *)(st.base + L.gradp);
     c->d_total_ctx = (uint32_t *)(st.base + L.total);
     c->cur = -1;                                      // no profiling records: they would need events
