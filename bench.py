@@ -30,11 +30,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# v_dot4_u32_u8: 4 MAC per lane, one wave-instruction per 4 cycles per SIMD (measured with
-# tools/ubench/valu_rate.hip: 16 lanes/clk, like every VOP3 op): 256 CU x 4 SIMD x 16 x 4 x 2.4 GHz
-DOT4_PEAK_TMACS = 256 * 4 * 16 * 4 * 2.4e9 / 1e12
 I8_MFMA_PEAK_TOPS = 5000.0                  # MI355X_MICROARCH.md, matrix cores: I8 = 2x BF16 = ~5 POP/s dense
 NSIMD = 256 * 4
+NCU = 256
 PEAK_CLOCK_HZ = 2.4e9
 
 
@@ -452,6 +450,14 @@ def main():
                 for name in ("ta_busy_frac", "mfma_busy_frac", "lds_active_frac"):
                     if name in u:
                         r[name] = u[name]
+                if "SQ_INSTS_LDS" in u:
+                    # a CU takes one ds_add_u32 / ds_write_b32 wave-instruction per 4 cycles (address + data register
+                    # transfer; measured 4.0 - 4.2 with tools/ubench/lds_add_rate.hip), whatever the SIMD it comes from
+                    r["lds_wave_insts_per_launch"] = u["SQ_INSTS_LDS"]
+                    r["lds_issue_frac_at_sustained_clock"] = u["SQ_INSTS_LDS"] * 4.0 / (NCU * t * clk)
+                shares = {"valu issue": r["valu_issue_frac_at_sustained_clock"], "matrix cores": r.get("mfma_busy_frac", 0.0),
+                          "LDS instruction path": r.get("lds_issue_frac_at_sustained_clock", 0.0)}
+                r["binds"] = max(shares, key=shares.get)
                 return r
             def roof_blur_mfma():
                 """k_blur runs on the matrix cores: its bound is MFMA issue, not HBM.  `achieved` counts the
@@ -471,10 +477,6 @@ def main():
             out["roofline_other"] = [roof(k) if k != "k_blur" else roof_blur_mfma() for k in alg if k != dom]
             out["roofline_binding"] = binding(dom)
             out["roofline_binding_other"] = [b for b in (binding(k) for k in alg if k != dom) if b]
-            t_blur = stage["k_blur"] * 1e-3
-            macs = 507.0 * W * H * B
-            out["valu"] = {"kernel": "k_blur", "achieved": macs / t_blur / 1e12, "peak": DOT4_PEAK_TMACS,
-                           "unit": "TMAC/s (u8 dot4)", "frac": macs / t_blur / 1e12 / DOT4_PEAK_TMACS}
             out["kernel_ms_per_step"] = stage
             out["step_kernel_ms"] = spread
         if overlapped is not None:

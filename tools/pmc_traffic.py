@@ -113,6 +113,8 @@ def main():
             e["mfma_busy_frac"] = cs["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)
         if "TA_TA_BUSY_sum" in cs:
             e["ta_busy_frac"] = cs["TA_TA_BUSY_sum"] / (256.0 * cyc)
+        if "SQ_INSTS_LDS" in cs:
+            e["SQ_INSTS_LDS"] = cs["SQ_INSTS_LDS"]
         if "SQ_LDS_IDX_ACTIVE" in cs:
             e["lds_active_frac"] = cs["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc)
         uw[k] = e
