@@ -6,6 +6,7 @@ instead of the compile-time WIDTH/HEIGHT of SIFTParameters.hpp:17-18.  Outputs
 have the reference's fixed shapes: MAX_KEYPOINTS keypoint slots (zero padded)
 and MAX_KEYPOINTS x 72 descriptor words.
 """
+import sys as _sys
 import ctypes as C
 
 import numpy as np
@@ -56,10 +57,9 @@ class SiftContext:
     def __del__(self):
         # prefer close() or the context manager; at interpreter shutdown the HIP runtime may already be
         # torn down, so nothing is destroyed then (the process is about to release everything anyway)
-        import sys
-        if sys is None or sys.is_finalizing():
-            return
         try:
+            if _sys is None or _sys.is_finalizing():     # module globals are cleared at shutdown: no import here
+                return
             self.close()
         except Exception:
             pass

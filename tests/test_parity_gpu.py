@@ -87,9 +87,10 @@ def test_4k_cap_engaged(sift, orc, synth_expected):
 
 
 @pytest.mark.parametrize("W,H", [(4, 1), (8, 3), (64, 64), (144, 144), (148, 150), (200, 176), (324, 201),
-                                 (260, 1000), (1000, 148), (4100, 150)])
+                                 (260, 1000), (1000, 148), (4100, 150), (256, 1024), (200, 1023), (200, 1025), (160, 2049)])
 def test_ragged_and_tiny_sizes(sift, orc, W, H):
-    """widths that are not multiples of 64/256, frames too small for any keypoint, thin frames"""
+    """widths that are not multiples of 64/256, frames too small for any keypoint, thin frames, heights at the
+    1024-row chunks of the row-count prefix"""
     img = orc.synth_frame(11, W, H)
     check_full(sift, orc, img)
 
