@@ -1,9 +1,10 @@
-// compact_kernel.h -- 7x7 cull on the sparse candidate list, border filter and raster-ordered
+// compact_kernel.h -- 7x7 cull on the candidate bit mask, border filter and raster-ordered
 // compaction into Keypoint_t[max_kp].
 //
 // Restates culling_hls + IsBestKeypoint (DetectKeypoints.cpp:567-750) and combine_keypoints_hls
 // (:372-439).  Pre-cull candidates are ~0.6 % of the frame, so everything after k_detect works
-// on its list and bit masks instead of on dense planes.  The compaction is rank based (per-row counts, then an in-row wave scan), which
+// on bit masks (one word per 64 pixels) and on the keys at the candidates instead of on dense planes.
+// The compaction is rank based (per-row counts, their prefix, then an in-row wave scan), which
 // reproduces the reference's raster order and its "first max_kp in raster order" cap without a
 // sort.
 #pragma once
@@ -15,20 +16,6 @@ namespace sift {
 
 
 struct kp_t { uint16_t x, y; uint32_t contrast; };   // Keypoint_t, SIFTParameters.hpp:79-85
-
-// bits [x0, x0+7) of row mask `m` (S segments), out-of-range bits read 0.  Branch-free: one
-// unaligned 2-byte load from a clamped byte offset (the mask is little-endian, so bit b of the
-// row is bit b & 7 of byte b >> 3); bits left of the row are shifted in as zeros, bits right of
-// it shifted out of the 16 loaded ones.  Calls for several rows overlap.
-__device__ __forceinline__ uint32_t mask_field7(const u64 *__restrict__ m, int S, int x0)
-{
-    const int bo = min(max(x0 >> 3, 0), S * 8 - 2);  // x0 in [-3, 64 S + 2]
-    const int sh = x0 - bo * 8;                      // -3 .. 18
-    uint16_t v16;
-    __builtin_memcpy(&v16, reinterpret_cast<const char *>(m) + bo, 2);
-    const uint32_t v = v16;
-    return (sh >= 0 ? v >> sh : v << -sh) & 0x7fu;
-}
 
 // (:393) keep only 71 < y < H-71 and 71 < x < W-71
 __device__ __forceinline__ u64 border_mask(int y, int seg, int W, int H)
@@ -43,59 +30,133 @@ __device__ __forceinline__ u64 border_mask(int y, int seg, int W, int H)
     return m;
 }
 
-// 7x7 cull, one lane per pre-cull candidate of k_detect's list.  A candidate survives iff its
-// Q15 edge ratio is strictly smaller than that of every OTHER candidate in the 7x7 window
-// (:728-731, :684; neighbours are pre-cull values).  Survivors get their bit in survmask and,
-// inside the border, count in rowcount[y] (both zeroed by k_detect).
-// grid: x = blocks of 256 (grid-stride over the list), y = frames.
+// 7x7 cull by position: one lane per 64-pixel word of the candidate mask, a wave = 64 consecutive words (two
+// rows of a 1080p frame).  A candidate survives iff its Q15 edge ratio is strictly smaller than that of every OTHER
+// candidate in the 7x7 window (:728-731, :684; neighbours are pre-cull values).
+//   * the seven rows of words around the lane's word come through a bounds-checked descriptor of the frame's
+//     mask (rows above and below the image read 0), each with the last dword of the word to its left and the
+//     first of the word to its right: 21 loads that neighbouring lanes share cache lines of;
+//   * per row three dwords P0..P2 = bits -3..28, 29..60, 61..92 of that window, so that the 7 neighbours of bit b in
+//     a row are v_alignbit(P1, P0, b) for b < 32 and v_alignbit(P2, P1, b) for b >= 32 (the shift takes b mod 32):
+//     two instructions per row and candidate, no memory access;
+//   * only candidates that HAVE a neighbour (few) read keys: they are parked in four slots, and after the bit
+//     loops their own key and their first neighbour's are requested together -- one round trip to the key
+//     plane per word, not one per candidate; further neighbours are looked at only while the candidate is
+//     still the best.
+// Every word of survmask is stored once (no atomics, nothing to clear beforehand); rowcount (zeroed by k_detect)
+// gets one atomic add per word with a survivor inside the border.
+// grid: x = ceil(H * S / 256), y = frames; block = 256
 __global__ __launch_bounds__(256) void k_cull(const u64 *__restrict__ candmask, const uint32_t *__restrict__ keyplane,
-                                              const uint32_t *__restrict__ list,
-                                              const uint32_t *__restrict__ listcount, u64 *__restrict__ survmask,
-                                              uint32_t *__restrict__ rowcount, int W, int H, int S, int list_cap, int Wl)
+                                              u64 *__restrict__ survmask, uint32_t *__restrict__ rowcount,
+                                              int W, int H, int S, int Wl)
 {
     const int frame = blockIdx.y;
-    const size_t fpix = (size_t)frame * (size_t)W * (size_t)H;
-    const uint32_t *__restrict__ kp = keyplane + fpix;
+    const int nwords = H * S;
+    const int w = blockIdx.x * 256 + (int)threadIdx.x;
+    if (w >= nwords) return;
     const size_t frow = (size_t)frame * H;
-    const u64 *__restrict__ cm = candmask + frow * S;
-    const uint32_t n = min(listcount[frame], (uint32_t)list_cap);
-    const uint32_t *__restrict__ fl = list + (size_t)frame * list_cap;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t e = fl[i];
-        const int y = (int)(e >> 16), x = (int)(e & 0xffffu);
-        const uint32_t ec = kp[(size_t)y * W + x] >> 8;
-        // candidates in the 7x7 window: 7 bits per row, row dy+3 at bits 7*(dy+3)
-        u64 nb = 0ull;
+    const int y = w / S, seg = w - y * S;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64 *>(candmask + frow * S), 0, nwords * 8, 0x00020000);
+    const uint32_t lmask = seg > 0 ? ~0u : 0u, rmask = seg < S - 1 ? ~0u : 0u;   // no word to the left / right of the row
+    uint32_t P0[7], P1[7], P2[7];
+    u64 c0 = 0ull;
 #pragma unroll
-        for (int dy = -3; dy <= 3; dy++) {
-            const int yy = y + dy;
-            const bool ok = yy >= 0 && yy < H;
-            const uint32_t f = mask_field7(cm + (size_t)(ok ? yy : 0) * S, S, x - 3);
-            nb |= (u64)(ok ? f : 0u) << (7 * (dy + 3));
-        }
-        nb &= ~(1ull << 24);                                         // not the keypoint itself (:728)
-        // the neighbours' keys, four loads in flight (a lane rarely has more neighbours)
-        bool best = true;
-        while (nb && best) {
-            uint32_t en[4];
-            bool has[4];
+    for (int r = 0; r < 7; r++) {
+        // row y + r - 3: an offset before the mask wraps to 4 GB, one past it lies beyond the descriptor: both read 0
+        const uint32_t off = (uint32_t)(w + (r - 3) * S) * 8u;
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 m = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
+        const uint32_t l = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(off - 4u), 0, 0) & lmask;
+        const uint32_t rr = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(off + 8u), 0, 0) & rmask;
+        P0[r] = __builtin_amdgcn_alignbit(m.x, l, 29);
+        P1[r] = __builtin_amdgcn_alignbit(m.y, m.x, 29);
+        P2[r] = __builtin_amdgcn_alignbit(rr, m.y, 29);
+        if (r == 3) c0 = (u64)m.x | (u64)m.y << 32;
+    }
+    u64 surv = 0ull;
+    if (c0) {                                                            // a third of the words hold a candidate
+        const uint32_t *__restrict__ kp = keyplane + (size_t)frame * (size_t)W * (size_t)H + (size_t)y * W + seg * 64;   // the word's bit 0
+        // a candidate with neighbours: nb = its 7x7 field (row r at bits 7r, bit 7r + c = column b - 3 + c, itself cleared)
+        auto resolve = [&](int b, u64 nb) -> bool {
+            const uint32_t ec = kp[b] >> 8;
+            bool best = true;
+            while (nb && best) {                                         // four keys in flight (a candidate rarely has more neighbours)
+                uint32_t en[4];
+                bool hn[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                has[u] = nb != 0ull;
-                const int k = has[u] ? __ffsll((long long)nb) - 1 : 24;   // 24: the keypoint itself
-                nb &= nb - 1;
-                en[u] = kp[(size_t)(y + k / 7 - 3) * W + (x + k % 7 - 3)] >> 8;
+                for (int u = 0; u < 4; u++) {
+                    hn[u] = nb != 0ull;
+                    const int k = hn[u] ? __ffsll((long long)nb) - 1 : 24;   // 24: the keypoint itself
+                    nb &= nb - 1;
+                    en[u] = kp[(k / 7 - 3) * W + (b + k % 7 - 3)] >> 8;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (hn[u] && !(ec < en[u])) best = false;            // strict (:730)
             }
+            return best;
+        };
+        int qb[4] = {0, 0, 0, 0};
+        u64 qn[4] = {0ull, 0ull, 0ull, 0ull};
+        int nq = 0;
+        // the slots are written through a switch so that they stay in registers
+        auto park = [&](int b, u64 nb) {
+            switch (nq) {
+            case 0: qb[0] = b; qn[0] = nb; break;
+            case 1: qb[1] = b; qn[1] = nb; break;
+            case 2: qb[2] = b; qn[2] = nb; break;
+            default: qb[3] = b; qn[3] = nb; break;
+            }
+            nq++;
+        };
+        auto bits = [&](uint32_t c, auto high) {
+            constexpr bool HIGH = decltype(high)::value;
+            while (c) {
+                const int b5 = __ffs((int)c) - 1;
+                c &= c - 1;
+                uint32_t f[7];
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (has[u] && !(ec < en[u])) best = false;           // strict (:730)
+                for (int r = 0; r < 7; r++) f[r] = __builtin_amdgcn_alignbit(HIGH ? P2[r] : P1[r], HIGH ? P1[r] : P0[r], (uint32_t)b5) & 0x7fu;
+                f[3] &= ~8u;                                             // not the keypoint itself (:728)
+                const int b = b5 + (HIGH ? 32 : 0);
+                if ((f[0] | f[1] | f[2]) | (f[3] | f[4] | f[5]) | f[6]) {
+                    const u64 nb = (u64)(f[0] | f[1] << 7 | f[2] << 14 | f[3] << 21) | (u64)(f[4] | f[5] << 7 | f[6] << 14) << 28;
+                    if (nq < 4) {
+                        park(b, nb);
+                    } else if (resolve(b, nb)) {
+                        surv |= 1ull << b;
+                    }
+                } else {
+                    surv |= 1ull << b;                                   // alone in its window
+                }
+            }
+        };
+        bits((uint32_t)c0, std::false_type{});
+        bits((uint32_t)(c0 >> 32), std::true_type{});
+        // parked candidates: own key and first neighbour's key of all of them in one round trip
+        uint32_t ec[4], e1[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            ec[j] = e1[j] = 0u;
+            if (j < nq) {
+                const int k = __ffsll((long long)qn[j]) - 1;
+                ec[j] = kp[qb[j]] >> 8;
+                e1[j] = kp[(k / 7 - 3) * W + (qb[j] + k % 7 - 3)] >> 8;
+            }
         }
-        if (best) {
-            const u64 bit = 1ull << (x & 63);
-            atomicOr(survmask + (frow + y) * S + (x >> 6), bit);
-            if (border_mask(y, x >> 6, Wl, H) & bit) atomicAdd(rowcount + frow + y, 1u);   // the border rule counts from the logical width
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (j < nq) {
+                bool best = ec[j] < e1[j];
+                const u64 rest = qn[j] & (qn[j] - 1);
+                if (best && rest) best = resolve(qb[j], rest);
+                if (best) surv |= 1ull << qb[j];
+            }
         }
     }
+    survmask[frow * S + w] = surv;
+    const int n = __popcll(surv & border_mask(y, seg, Wl, H));          // the border rule counts from the logical width
+    if (n) atomicAdd(rowcount + frow + y, (uint32_t)n);
 }
 
 // Exclusive prefix of the row counts: rowbase[y] = keypoints in rows above y, rowbase[H] = the frame's total.

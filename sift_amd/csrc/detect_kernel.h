@@ -24,10 +24,9 @@
 // Outputs per frame
 //   candmask[y][seg]  u64, bit = pre-cull candidate (raster order; every word of the strip written)
 //   keyplane[y][x]    u32, written ONLY at candidates: (E_q15 << 8) | |D2|
-//   list[]            the candidates as (y << 16 | x), appended per strip (order irrelevant)
 //   gradp             gradp_pack(code, mag) per pair of pixels, rows interleaved by four (gradp_quad_word; internal, 2 B/pixel)
 //   gradfull[y][x]    Grad_t {ang, mag}                        (optional, sift_detect API)
-// and it zeroes survmask / rowcount, which k_cull fills with atomics.
+// and it zeroes rowcount, which k_cull fills with atomics.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -168,8 +167,7 @@ __device__ __forceinline__ int edge_at(const uint4 *__restrict__ fp, int W4, int
 constexpr int DETECT_ROWS = 32;                       // most rows per strip (LDS is sized for it)
 // LDS queue of the pixels that passed the extremum and contrast tests.  A row adds at most 256
 // entries (4 pixels x 64 lanes); when the next three rows might not fit the queue is drained (edge
-// test, survivors appended to the frame's list) in the middle of the strip, so no density of
-// extrema can overflow it.  (A strict maximum and a strict minimum may be neighbours, so
+// test) in the middle of the strip, so no density of extrema can overflow it.  (A strict maximum and a strict minimum may be neighbours, so
 // "never 8-adjacent" bounds only each kind by 1/4; real frames stay near 1 %.)
 constexpr int DETECT_QUEUE = 256 * DETECT_ROWS / 4;
 static_assert(DETECT_QUEUE >= 3 * 256, "three rows must fit after a drain");
@@ -179,10 +177,9 @@ static_assert(DETECT_QUEUE >= 3 * 256, "three rows must fit after a drain");
 template <bool FULLGRAD>
 __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
                                                u64 *__restrict__ candmask, uint32_t *__restrict__ keyplane,
-                                               u64 *__restrict__ survmask, uint32_t *__restrict__ rowcount,
-                                               uint32_t *__restrict__ list, uint32_t *__restrict__ listcount,
+                                               uint32_t *__restrict__ rowcount,
                                                uint16_t *__restrict__ gradp, uint32_t *__restrict__ gradfull,
-                                               int W, int H, int S, int contrastTh, int list_cap, int rows, int qcap, int Wl)
+                                               int W, int H, int S, int contrastTh, int rows, int qcap, int Wl)
 {
     __shared__ uint32_t queue[DETECT_QUEUE];
     __shared__ u64 cmap[DETECT_ROWS * 4];             // candidate bits of the strip: row-major, 4 words per row
@@ -260,35 +257,19 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
     uint32_t qcount = 0;                              // wave-uniform
     const size_t frow = (size_t)frame * H;
     // Edge test on the queue, one lane per entry; what passes is a pre-cull candidate: its key and
-    // its bit in cmap are written, and the entries are compacted in place and appended to the frame's
-    // list.  Runs at the end of the strip and whenever the queue is nearly full after a row.
+    // its bit in cmap are written.  Runs at the end of the strip and whenever the queue is nearly full after a row.
     auto drain = [&]() {
         __syncthreads();
-        uint32_t ccount = 0;                          // wave-uniform
         for (uint32_t i0 = 0; i0 < qcount; i0 += 64) {
             const bool live = i0 + lane < qcount;
             const uint32_t e = live ? queue[i0 + lane] : 0u;
             const int y = (int)(e >> 16), x = (int)(e & 0xffffu);
             int ac;
             const int ec = edge_at(fp, W4, W, H, y, x, &ac);
-            const bool cand = live && ec >= 0;                           // :200
-            if (cand) {
+            if (live && ec >= 0) {                                       // :200
                 keyplane[fpix + (size_t)y * W + x] = ((uint32_t)ec << 8) | (uint32_t)ac;
                 atomicOr(&cmap[(y - ys) * 4 + ((x >> 6) & 3)], 1ull << (x & 63));
             }
-            const u64 bal = __ballot(cand);
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-            if (cand) queue[ccount + below] = e;      // ccount + below <= i0 + lane: nothing unread is overwritten
-            ccount += (uint32_t)__popcll(bal);
-        }
-        __syncthreads();
-        if (ccount) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(listcount + frame, ccount);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            uint32_t *__restrict__ fl = list + (size_t)frame * list_cap;
-            for (uint32_t i = lane; i < ccount; i += 64)
-                if (base + i < (uint32_t)list_cap) fl[base + i] = queue[i];
         }
         __syncthreads();
         qcount = 0;
@@ -420,14 +401,11 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
     }
 
     drain();
-    // every mask word of the strip: candidates as found, survivors empty (k_cull sets them)
+    // every candidate mask word of the strip (k_cull writes every word of the survivors' mask)
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const int wi = lane + 64 * k, row = wi >> 2, seg = blockIdx.x * 4 + (wi & 3);
-        if (ys + row < ye && seg < S) {
-            candmask[(frow + ys + row) * S + seg] = cmap[wi];
-            survmask[(frow + ys + row) * S + seg] = 0ull;
-        }
+        if (ys + row < ye && seg < S) candmask[(frow + ys + row) * S + seg] = cmap[wi];
     }
     if (blockIdx.x == 0 && lane < ye - ys) rowcount[frow + ys + lane] = 0u;
 }

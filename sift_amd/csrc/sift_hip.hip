@@ -251,8 +251,6 @@ struct sift_hip_ctx {
     uint8_t *d_img = nullptr;             // staging for host-buffer entry points
     uint4 *d_pyr = nullptr;               // {src, G1, G2, G3} dwords per group of 4 pixels
     unsigned long long *d_cand = nullptr, *d_surv = nullptr;   // [H][S] bit masks
-    uint32_t *d_list = nullptr, *d_listcount = nullptr;        // k_detect's candidate list per frame
-    int list_cap = 0;
     uint32_t *d_key = nullptr;            // (E<<8)|contrast at candidates
     uint32_t *d_rowcount = nullptr;       // [H]
     uint32_t *d_rowbase = nullptr;        // [H + 1] exclusive prefix of d_rowcount (k_rowprefix)
@@ -395,7 +393,6 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
 {
     const int W = c->W, H = c->H, S = c->S;
     c->last_frames = nframes;
-    HIP_TRY(hipMemsetAsync(c->d_listcount, 0, (size_t)nframes * 4, s));
     // k_blur_mfma addresses a frame's pyr plane (4 bytes per pixel) through one 32-bit buffer descriptor
     if (c->blur_mfma && c->npix * 4 < (1ull << 32)) {
         StageTimer t(c, ST_BLUR, s);
@@ -432,20 +429,16 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
         dim3 grid(spans, (H + drows - 1) / drows, nframes);
         if (d_gradfull)
             hipLaunchKernelGGL(sift::k_detect<true>, grid, dim3(64), 0, s, c->d_pyr, c->d_cand, c->d_key,
-                               c->d_surv, c->d_rowcount, c->d_list, c->d_listcount, c->d_gradp, d_gradfull, W, H, S,
-                               th, c->list_cap, drows, c->detect_queue, c->Wl);
+                               c->d_rowcount, c->d_gradp, d_gradfull, W, H, S, th, drows, c->detect_queue, c->Wl);
         else
             hipLaunchKernelGGL(sift::k_detect<false>, grid, dim3(64), 0, s, c->d_pyr, c->d_cand, c->d_key,
-                               c->d_surv, c->d_rowcount, c->d_list, c->d_listcount, c->d_gradp,
-                               (uint32_t *)nullptr, W, H, S, th, c->list_cap, drows, c->detect_queue, c->Wl);
+                               c->d_rowcount, c->d_gradp, (uint32_t *)nullptr, W, H, S, th, drows, c->detect_queue, c->Wl);
     }
     {
         StageTimer t(c, ST_CULL, s);
-        // grid-stride over the candidate list (~0.6 % of the pixels)
-        const int blocks = (int)std::min<size_t>(1024, (c->npix / 128 + 255) / 256 + 1);
-        dim3 grid(blocks, nframes);
-        hipLaunchKernelGGL(sift::k_cull, grid, dim3(256), 0, s, c->d_cand, c->d_key, c->d_list, c->d_listcount,
-                           c->d_surv, c->d_rowcount, W, H, S, c->list_cap, c->Wl);
+        // one lane per 64-pixel word of the candidate mask
+        hipLaunchKernelGGL(sift::k_cull, dim3((H * S + 255) / 256, nframes), dim3(256), 0, s, c->d_cand, c->d_key,
+                           c->d_surv, c->d_rowcount, W, H, S, c->Wl);
     }
     {
         StageTimer t(c, ST_EMIT, s);
@@ -636,9 +629,6 @@ int sift_hip_create_geometry(sift_hip_ctx **out, int device, int width, int heig
     A((void **)&c->d_img, B * np);
     if (e == hipSuccess && logical_width != width) e = hipMemset(c->d_img, 0, B * np);   // the padding columns stay zero
     A((void **)&c->d_pyr, B * np * 4);
-    c->list_cap = (int)std::min<size_t>(np / 2 + 64, 0x7fffffff);
-    A((void **)&c->d_list, B * (size_t)c->list_cap * 4);
-    A((void **)&c->d_listcount, B * 4);
     A((void **)&c->d_cand, B * HS * 8);
     A((void **)&c->d_surv, B * HS * 8);
     A((void **)&c->d_key, B * np * 4);
@@ -673,7 +663,7 @@ void sift_hip_destroy(sift_hip_ctx *c)
     if (!c) return;
     DevGuard g(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->d_img, c->d_pyr, c->d_list, c->d_listcount, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_rowbase, c->d_gradp,
+    void *ptrs[] = {c->d_img, c->d_pyr, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_rowbase, c->d_gradp,
                     c->d_gradfull, c->d_final, c->d_findex, c->d_nvalid, c->d_tfinal, c->d_tindex, c->d_tdesc, c->d_tnvalid, c->d_bgr, c->d_match, c->d_kps, c->d_desc, c->d_total, c->d_total_ctx, c->d_ori, c->d_tab, c->d_qtab, c->d_gate, c->d_spec};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &ps : c->prof)
@@ -1279,15 +1269,13 @@ std::mutex g_static_mu;
 
 // the buffers of a call, carved out of the array behind the tables (256-byte aligned)
 struct StaticLayout {
-    size_t pyr, list, listcount, cand, surv, key, rowcount, rowbase, gradp, total, end;
+    size_t pyr, cand, surv, key, rowcount, rowbase, gradp, total, end;
     StaticLayout(int W, int H, int nframes)
     {
         const size_t B = (size_t)nframes, np = (size_t)W * H, HS = (size_t)H * (size_t)((W + 63) / 64);
         size_t o = STATIC_TABLE_BYTES;
         auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
         pyr = take(B * np * 4);
-        list = take(B * (np / 2 + 64) * 4);
-        listcount = take(B * 4);
         cand = take(B * HS * 8);
         surv = take(B * HS * 8);
         key = take(B * np * 4);
@@ -1372,10 +1360,7 @@ int sift_hip_detect_and_compute_static(int device, const uint8_t *d_imgs, int nf
     c->W = width; c->Wl = width; c->H = height; c->S = (width + 63) / 64;
     c->npix = (size_t)width * height;
     c->max_batch = nframes;
-    c->list_cap = (int)std::min<size_t>(c->npix / 2 + 64, 0x7fffffff);
     c->d_pyr = (uint4 *)(st.base + L.pyr);
-    c->d_list = (uint32_t *)(st.base + L.list);
-    c->d_listcount = (uint32_t *)(st.base + L.listcount);
     c->d_cand = (unsigned long long *)(st.base + L.cand);
     c->d_surv = (unsigned long long *)(st.base + L.surv);
     c->d_key = (uint32_t *)(st.base + L.key);
@@ -1385,8 +1370,8 @@ int sift_hip_detect_and_compute_static(int device, const uint8_t *d_imgs, int nf
     c->d_total_ctx = (uint32_t *)(st.base + L.total);
     c->cur = -1;                                      // no profiling records: they would need events
     // The array keeps the previous call's contents.  What must start at zero is cleared by the
-    // kernels themselves, as for a context's scratch: the list counts by run_detect's memset, the
-    // survivor masks and row counts by k_detect; everything else is written before it is read.
+    // kernels themselves, as for a context's scratch: the row counts by k_detect; everything else is
+    // written before it is read.
     if (int r = run_detect(c, d_imgs, nframes, nullptr, (sift::kp_t *)d_kps, d_total, contrastTh, s)) return r;
     return run_describe<sift::GRAD_PACKED16, sift::DESC_FUSED>(c, c->d_gradp, nframes, (const sift::kp_t *)d_kps, nullptr,
                                                                nullptr, d_desc, s);
