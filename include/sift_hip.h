@@ -230,8 +230,8 @@ int sift_hip_gray_from_bgr_dev(sift_hip_ctx *ctx, const uint8_t *d_bgr, int nfra
  * d_total (nframes) are the caller's device buffers on `device`; max_keypoints is fixed at
  * SIFT_HIP_MAX_KEYPOINTS; the work is enqueued on `stream` (NULL = the legacy default stream) and
  * not waited for.
- * Limit: sift_hip_static_scratch_needed(width, height, nframes) (about 12.3 bytes per pixel and
- * frame + 0.26 MB) must not exceed SIFT_HIP_STATIC_SCRATCH_BYTES -- one 1920x1080 frame or six
+ * Limit: sift_hip_static_scratch_needed(width, height, nframes) (about 10.3 bytes per pixel and
+ * frame + 0.26 MB) must not exceed SIFT_HIP_STATIC_SCRATCH_BYTES -- one 1920x1080 frame or ten
  * 640x480 frames fit; larger calls fail with SIFT_HIP_EINVAL and a message that says so.
  * The first call on a device, and the first after the width changed, rebuilds the descriptor tables on
  * the host, copies them on `stream` and waits for that copy: make that call outside stream capture.
