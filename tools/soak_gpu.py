@@ -42,6 +42,9 @@ def main():
                 img[:, W // 2:] += 90
             img = np.clip(img + 128, 0, 255).astype(np.uint8)
         th = int(rng.integers(1, 30))
+        if case % 7 == 6:                                             # dense candidates: clusters in every 7x7 window, word edges included
+            img = rng.integers(0, 256, img.shape).astype(np.uint8) if case % 2 else (img ^ rng.integers(0, 8, img.shape).astype(np.uint8))
+            th = int(rng.integers(0, 3))
         _, _, n, total = T.check_full(sift, orc, img, th=th)
         nk += n
         if case % 3 == 0:                                             # the Cam1 geometry and the blur on the vector ALUs
