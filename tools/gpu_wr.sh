@@ -6,7 +6,7 @@ TAG=${1:-wr}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-overlap --no-other-configs --no-end-to-end --steps 2 --warmup 1 --no-profile-events"
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-overlap --no-other-configs --no-end-to-end --steps 2 --warmup 1 --no-profile-events --no-check"
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $BENCH > "$OUT/write.json" 2> "$OUT/write.err" || { echo "write pass failed"; tail -5 "$OUT/write.err"; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $BENCH > "$OUT/fetch.json" 2> "$OUT/fetch.err" || { echo "fetch pass failed"; tail -5 "$OUT/fetch.err"; exit 1; }
 python3 - "$OUT" <<'PY'
