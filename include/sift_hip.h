@@ -247,6 +247,22 @@ unsigned long sift_hip_static_scratch_needed(int width, int height, int nframes)
 /* Block until everything this context enqueued has finished. */
 int sift_hip_sync(sift_hip_ctx *ctx);
 
+/* ---- further octaves (extension) ------------------------------------------ */
+
+/* The reference processes one octave (sift_detect's three blurs of the input frame, DetectKeypoints.cpp:1073-1175);
+ * SURVEY.md 8(f)4 lists a multi-octave mode as an optional extension, with nothing in the reference to pin it to.
+ * This build defines it by composition: the input frame of the next octave is every second pixel of every second
+ * row -- pixel (2x, 2y) -- of one blurred plane of the frame just processed (plane 1 = the 5x5 table's G1, 2 = the
+ * 11x11 table's G2, which keypoints are detected on, 3 = the 19x19 table's G3), (width/2) x (height/2) pixels with
+ * pitch width/2, and that frame goes through the unchanged single-octave entry points of a context created for that
+ * size.  Keypoint coordinates are in the octave's own pixels (multiply by 2^octave for the input frame's).
+ *
+ * sift_hip_next_octave_dev: frames frame_first .. frame_first + nframes - 1 of the LAST detect call on `ctx`, into
+ * d_dst (device, nframes * (width/2) * (height/2) bytes); enqueued on `stream` (NULL = the context's own), which must be the stream of that
+ * call (one stream per context).  sift_hip_next_octave: one frame into a host buffer, blocking. */
+int sift_hip_next_octave_dev(sift_hip_ctx *ctx, int frame_first, int nframes, int plane, uint8_t *d_dst, void *stream);
+int sift_hip_next_octave(sift_hip_ctx *ctx, int frame, int plane, uint8_t *dst);
+
 /* ---- introspection (tests, bench) ---------------------------------------- */
 
 /* Stage planes of frame `frame` of the LAST detect call on this context,

@@ -147,6 +147,24 @@ def detect_and_compute(img, contrast_th=15, geometry=0):
     return kps, desc, total
 
 
+def next_octave(img, plane=2):
+    """the build's definition of a further octave (include/sift_hip.h; the reference runs one octave, SURVEY.md
+    8(f)4): pixel (2x, 2y) of blurred plane `plane` of `img` -> uint8[H // 2, W // 2]"""
+    H, W = np.asarray(img).shape
+    g = blur(img)[plane - 1]
+    return np.ascontiguousarray(g[0:2 * (H // 2):2, 0:2 * (W // 2):2])
+
+
+def detect_and_compute_octaves(img, noctaves, contrast_th=15, plane=2):
+    """[(kps, desc, total)] per octave: detect_and_compute on img, then on next_octave of it, ..."""
+    out = []
+    for o in range(noctaves):
+        out.append(detect_and_compute(img, contrast_th))
+        if o + 1 < noctaves:
+            img = next_octave(img, plane)
+    return out
+
+
 def geometry_masks(geometry):
     """-> (window, radius, circle mask [m, m], xstart[9], ystart[9], orientation mask [window, window])"""
     win, rad, m = ((71, 35, 25), (81, 40, 29))[geometry]

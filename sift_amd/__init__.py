@@ -7,11 +7,11 @@ needs libsift_hip.so and a gfx950 device and raises otherwise.
 from .capi import (DESC_SIZE, DMATCH_DTYPE, GRAD_DTYPE, KP_DTYPE, MAX_KEYPOINTS, STAGE_NAMES, SiftHipError, build_library,
                    library_path, load_library)
 from .hw_sift import (SiftContext, compute_descriptor, compute_main_orientation, sift_detect,
-                      sift_detect_and_compute)
+                      sift_detect_and_compute, sift_detect_and_compute_octaves)
 from .synth import synth_frame
 
 __all__ = [
     "DESC_SIZE", "DMATCH_DTYPE", "GRAD_DTYPE", "KP_DTYPE", "MAX_KEYPOINTS", "STAGE_NAMES", "SiftHipError", "build_library",
     "library_path", "load_library", "SiftContext", "compute_descriptor", "compute_main_orientation",
-    "sift_detect", "sift_detect_and_compute", "synth_frame",
+    "sift_detect", "sift_detect_and_compute", "sift_detect_and_compute_octaves", "synth_frame",
 ]

@@ -61,4 +61,19 @@ __global__ __launch_bounds__(256) void k_pad_rows(const uint8_t *__restrict__ sr
     reinterpret_cast<uint32_t *>(dst + ((size_t)blockIdx.z * H + y) * W)[xq] = v;
 }
 
+// Extension (the reference runs one octave; SURVEY.md 8(f)4 lists a multi-octave mode as optional): the next
+// octave's input frame = every second pixel of every second row of one blurred plane (1 = 5x5, 2 = 11x11,
+// 3 = 19x19 table) of the frames a context has just processed, read from its pyr words.
+// W4: groups per internal row; the output is (Wl/2) x (H/2) with pitch Wl/2.
+// grid: x = ceil(Wl/2 / 256), y = H/2, z = frames; block = 256
+__global__ __launch_bounds__(256) void k_next_octave(const uint4 *__restrict__ pyr, uint8_t *__restrict__ dst, int W4, int H, int W2, int H2,
+                                                     int plane)
+{
+    const int x2 = blockIdx.x * blockDim.x + threadIdx.x, y2 = blockIdx.y;
+    if (x2 >= W2) return;
+    const uint4 q = pyr[((size_t)blockIdx.z * H + 2 * y2) * W4 + (x2 >> 1)];       // pixel 2 x2 lies in group x2 / 2, byte 2 (x2 & 1)
+    const uint32_t w = plane == 1 ? q.y : plane == 2 ? q.z : q.w;
+    dst[((size_t)blockIdx.z * H2 + y2) * W2 + x2] = (uint8_t)(w >> (16 * (x2 & 1)));
+}
+
 }  // namespace sift

@@ -1377,6 +1377,41 @@ int sift_hip_detect_and_compute_static(int device, const uint8_t *d_imgs, int nf
                                                                nullptr, d_desc, s);
 }
 
+int sift_hip_next_octave_dev(sift_hip_ctx *c, int frame_first, int nframes, int plane, uint8_t *d_dst, void *stream)
+{
+    if (int r = check_ctx(c)) return r;
+    if (!d_dst) return fail(SIFT_HIP_EINVAL, "null buffer");
+    if (plane < 1 || plane > 3) return fail(SIFT_HIP_EINVAL, "plane must be 1, 2 or 3");
+    if (nframes < 1 || frame_first < 0 || frame_first + nframes > c->last_frames)
+        return fail(SIFT_HIP_EINVAL, "frames outside the last call's batch");
+    const int W2 = c->Wl / 2, H2 = c->H / 2;
+    if (W2 < 1 || H2 < 1) return fail(SIFT_HIP_EINVAL, "frame too small for another octave");
+    DevGuard g(c->device);
+    hipLaunchKernelGGL(sift::k_next_octave, dim3((W2 + 255) / 256, H2, nframes), dim3(256), 0, stream ? (hipStream_t)stream : c->stream,
+                       c->d_pyr + (size_t)frame_first * (c->npix / 4), d_dst, c->W / 4, c->H, W2, H2, plane);
+    HIP_TRY(hipGetLastError());
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_next_octave(sift_hip_ctx *c, int frame, int plane, uint8_t *dst)
+{
+    if (int r = check_ctx(c)) return r;
+    if (!dst) return fail(SIFT_HIP_EINVAL, "null buffer");
+    const size_t n = (size_t)(c->Wl / 2) * (size_t)(c->H / 2);
+    if (!n) return fail(SIFT_HIP_EINVAL, "frame too small for another octave");
+    DevGuard g(c->device);
+    uint8_t *d = nullptr;
+    HIP_TRY(hipMalloc(&d, n));
+    int r = sift_hip_next_octave_dev(c, frame, 1, plane, d, c->stream);
+    hipError_t e = hipSuccess;
+    if (!r) e = hipMemcpyAsync(dst, d, n, hipMemcpyDeviceToHost, c->stream);
+    if (!r && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (r) return r;
+    if (e != hipSuccess) return fail(SIFT_HIP_EHIP, "next octave", e);
+    return SIFT_HIP_OK;
+}
+
 int sift_hip_debug_planes(sift_hip_ctx *c, int frame, uint8_t *g1, uint8_t *g2, uint8_t *g3, uint16_t *cand,
                           int32_t *eratio, uint16_t *surv)
 {

@@ -176,6 +176,16 @@ class SiftContext:
         check(self._lib.sift_hip_sync(self._h))
 
     # -- introspection ------------------------------------------------------------
+    def next_octave(self, frame=0, plane=2):
+        """extension: the next octave's input frame, pixel (2x, 2y) of blurred plane `plane` (1, 2 or 3) of frame
+        `frame` of the last detect call -> uint8[height // 2, width // 2]"""
+        out = np.empty((self.height // 2, self.width // 2), np.uint8)
+        check(self._lib.sift_hip_next_octave(self._h, int(frame), int(plane), _vp(out)))
+        return out
+
+    def next_octave_dev(self, frame_first, nframes, d_dst, plane=2, stream=None):
+        check(self._lib.sift_hip_next_octave_dev(self._h, int(frame_first), int(nframes), int(plane), _dp(d_dst), _dp(stream)))
+
     def debug_planes(self, frame=0):
         H, W = self.height, self.width
         out = dict(g1=np.empty((H, W), np.uint8), g2=np.empty((H, W), np.uint8), g3=np.empty((H, W), np.uint8),
@@ -269,6 +279,19 @@ def sift_detect_and_compute(pSrcImage, contrastTh=15):
     """HW_SIFT.cpp:16-50 -> (pKeypoints[10000], pDesc[10000,72])"""
     pSrcImage = np.asarray(pSrcImage)
     return _ctx_for(pSrcImage.shape).sift_detect_and_compute(pSrcImage, contrastTh)
+
+
+def sift_detect_and_compute_octaves(pSrcImage, noctaves, contrastTh=15, plane=2):
+    """extension (include/sift_hip.h, "further octaves"): [(pKeypoints[10000], pDesc[10000,72])] per octave; octave
+    o + 1 is pixel (2x, 2y) of blurred plane `plane` of octave o, coordinates are in the octave's own pixels"""
+    img = np.asarray(pSrcImage)
+    out = []
+    for o in range(int(noctaves)):
+        ctx = _ctx_for(img.shape)
+        out.append(ctx.sift_detect_and_compute(img, contrastTh))
+        if o + 1 < int(noctaves):
+            img = ctx.next_octave(0, plane)
+    return out
 
 
 def sift_detect(pSrcImage, contrastTh=15):
