@@ -191,72 +191,90 @@ __global__ __launch_bounds__(1024) void k_rowprefix(const uint32_t *__restrict__
     }
 }
 
-// One wave per image row (+ one extra wave per frame for padding / totals: total_ctx is the
-// context's own copy of the uncapped count, which the fused describe kernel reads; total_out the
-// caller's, optional).  rowbase: k_rowprefix's exclusive prefix of the row counts.
-// grid: x = ceil((H+1)/4) blocks of 256, y = frames.
+// Keypoints in raster order: rank = keypoints in the rows above (rowbase: k_rowprefix's exclusive prefix of the
+// row counts) + survivors inside the border before the pixel in its row (wave scan over the row's mask words).
+// One extra wave per frame pads the array and writes the totals: total_ctx is the context's own copy of the
+// uncapped count, which the fused describe kernel reads; total_out the caller's, optional.
+// A wave takes R = 64 / S whole rows when a row's mask has at most 32 words (two rows of a 1080p frame, six of a
+// 640-pixel one), else one row in passes of 64 words; lane -> (row r = lane / S, word lane - r S).
+// grid: x = ceil((ceil(H / R) + 1) / 4) blocks of 256, y = frames.
 __global__ __launch_bounds__(256) void k_emit(const u64 *__restrict__ survmask,
                                               const uint32_t *__restrict__ keyplane,
                                               const uint32_t *__restrict__ rowbase, kp_t *__restrict__ kps,
                                               uint32_t *__restrict__ total_ctx, uint32_t *__restrict__ total_out,
-                                              int W, int H, int S, int max_kp, int Wl)
+                                              int W, int H, int S, int max_kp, int Wl, int R)
 {
-    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), nw = (H + R - 1) / R;
     const int lane = threadIdx.x & 63;
-    if (y > H) return;
+    if (wv > nw) return;
     const size_t frow = (size_t)blockIdx.y * H;
     const uint32_t *__restrict__ rb = rowbase + (size_t)blockIdx.y * (H + 1);
     kp_t *__restrict__ out = kps + (size_t)blockIdx.y * max_kp;
 
-    // keypoints in the rows above (k_rowprefix; y == H: the frame total) and, requested together with
-    // them, the row's first 64 mask segments, so that the wave waits for memory once before it reads the keys
-    uint32_t base = rb[y];
-    u64 m0 = 0ull;
-    if (y < H) {
-        if (lane < S) m0 = survmask[(frow + y) * S + lane];
-        if (rb[y + 1] == base) return;               // nothing to emit from this row
-    }
-
-    if (y == H) {
-        // padding (:428-436) and the uncapped total (nKeypointsTotal, :405-406)
+    if (wv == nw) {
+        // one more wave per frame: padding (:428-436) and the uncapped total (nKeypointsTotal, :405-406)
+        const uint32_t total = rb[H];
         if (lane == 0) {
-            total_ctx[blockIdx.y] = base;
-            if (total_out) total_out[blockIdx.y] = base;
+            total_ctx[blockIdx.y] = total;
+            if (total_out) total_out[blockIdx.y] = total;
         }
-        const uint32_t first = base < (uint32_t)max_kp ? base : (uint32_t)max_kp;
+        const uint32_t first = total < (uint32_t)max_kp ? total : (uint32_t)max_kp;
         u64 *o64 = reinterpret_cast<u64 *>(out);
         for (uint32_t i = first + lane; i < (uint32_t)max_kp; i += 64) o64[i] = 0ull;
         return;
     }
-    if (base >= (uint32_t)max_kp) return;            // cap reached above this row (:409)
-
-    const uint32_t *__restrict__ kp = keyplane + (size_t)blockIdx.y * (size_t)W * (size_t)H + (size_t)y * W;
-    for (int s0 = 0; s0 < S; s0 += 64) {
-        const int seg = s0 + lane;
-        u64 m = 0ull;
-        if (seg < S) m = (s0 == 0 ? m0 : survmask[(frow + y) * S + seg]) & border_mask(y, seg, Wl, H);
-        const uint32_t n = (uint32_t)__popcll(m);
-        // inclusive wave scan of n
+    const uint32_t *__restrict__ kpf = keyplane + (size_t)blockIdx.y * (size_t)W * (size_t)H;
+    auto emit = [&](u64 m, uint32_t idx, int y, int seg) {
+        const uint32_t *__restrict__ kp = kpf + (size_t)y * W + seg * 64;
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (idx < (uint32_t)max_kp) {                                // the first max_kp in raster order (:409)
+                kp_t k;
+                k.x = (uint16_t)(seg * 64 + b);
+                k.y = (uint16_t)y;
+                k.contrast = kp[b] & 0xffu;
+                out[idx] = k;
+            }
+            idx++;
+        }
+    };
+    // inclusive wave scan
+    auto scan = [&](uint32_t n) {
         uint32_t inc = n;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t t = __shfl_up(inc, o);
             if (lane >= o) inc += t;
         }
-        uint32_t idx = base + inc - n;
-        while (m) {
-            const int b = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            if (idx < (uint32_t)max_kp) {
-                const int x = seg * 64 + b;
-                kp_t k;
-                k.x = (uint16_t)x;
-                k.y = (uint16_t)y;
-                k.contrast = kp[x] & 0xffu;
-                out[idx] = k;
-            }
-            idx++;
-        }
+        return inc;
+    };
+
+    if (R > 1) {                                                         // wave-uniform: S <= 32
+        int r = 0;
+        for (int k = 1; k < R; k++) r += lane >= k * S;
+        const int seg = lane - r * S, y = wv * R + r;
+        const bool live = lane < R * S && y < H;
+        // keypoints in the rows above (k_rowprefix) and the row's mask word, requested together
+        const uint32_t base = rb[live ? y : 0];
+        u64 m = live ? survmask[(frow + y) * S + seg] : 0ull;
+        m &= border_mask(y, seg, Wl, H);
+        const uint32_t n = (uint32_t)__popcll(m);
+        const uint32_t inc = scan(n);
+        const uint32_t before = __shfl(inc, max(r * S - 1, 0));          // inclusive count at the end of the row before, in this wave
+        emit(m, base + inc - n - (r ? before : 0u), y, seg);
+        return;
+    }
+    const int y = wv;
+    uint32_t base = rb[y];
+    if (rb[y + 1] == base || base >= (uint32_t)max_kp) return;           // nothing to emit from this row / cap reached above it
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int seg = s0 + lane;
+        u64 m = 0ull;
+        if (seg < S) m = survmask[(frow + y) * S + seg] & border_mask(y, seg, Wl, H);
+        const uint32_t n = (uint32_t)__popcll(m);
+        const uint32_t inc = scan(n);
+        emit(m, base + inc - n, y, seg);
         base += __shfl(inc, 63);
     }
 }

@@ -442,10 +442,11 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
     }
     {
         StageTimer t(c, ST_EMIT, s);
-        dim3 grid((H + 1 + 3) / 4, nframes);
+        const int R = S <= 32 ? 64 / S : 1;            // whole rows per wave
+        dim3 grid(((H + R - 1) / R + 1 + 3) / 4, nframes);
         hipLaunchKernelGGL(sift::k_rowprefix, dim3(nframes), dim3(1024), 0, s, c->d_rowcount, c->d_rowbase, H);
         hipLaunchKernelGGL(sift::k_emit, grid, dim3(256), 0, s, c->d_surv, c->d_key, c->d_rowbase, d_kps,
-                           c->d_total_ctx, d_total, W, H, S, c->max_kp, c->Wl);
+                           c->d_total_ctx, d_total, W, H, S, c->max_kp, c->Wl, R);
     }
     HIP_TRY(hipGetLastError());
     return SIFT_HIP_OK;
