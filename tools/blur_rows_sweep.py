@@ -1,34 +1,40 @@
-"""GPU box: k_blur time against the strip length (sift_hip_set_blur_rows) for small batches.
-usage: python tools/blur_rows_sweep.py [--width 1920 --height 1080]"""
-import argparse
+#!/usr/bin/env python3
+"""GPU box: k_blur time per 256-frame launch for several strip lengths (sift_hip_set_blur_rows).
+usage: python tools/blur_rows_sweep.py [rows ...]"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-import sift_amd  # noqa: E402
-from sift_amd.synth import synth_frame  # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--width", type=int, default=1920)
-ap.add_argument("--height", type=int, default=1080)
-a = ap.parse_args()
-W, H, K = a.width, a.height, 10000
-for B in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64):
-    imgs = np.stack([synth_frame(1 + s, W, H) for s in range(B)])
-    with sift_amd.SiftContext(W, H, max_batch=B) as ctx:
-        d_img = torch.from_numpy(imgs).cuda()
-        d_kps = torch.zeros((B, K, 2), dtype=torch.int32, device="cuda")
-        d_desc = torch.zeros((B, K, 72), dtype=torch.int32, device="cuda")
-        ctx.set_profiling(8)
-        out = []
-        for rows in (0,):
-            ctx.set_blur_rows(rows)
-            for _ in range(8):
-                ctx.detect_and_compute_dev(d_img, B, d_kps, d_desc)
+
+def main():
+    import sift_amd as sift
+    from sift_amd.synth import synth_frames_torch
+    W, H, B = 1920, 1080, 256
+    dev = torch.device("cuda:0")
+    rows = [int(a) for a in sys.argv[1:]] or [0, 1080, 540, 360, 270, 216, 180, 135]
+    rows = rows + rows                                            # twice round: clocks and caches settle during the first
+    d_img = synth_frames_torch(range(1, B + 1), W, H, dev)
+    with sift.SiftContext(W, H, max_batch=B) as ctx:
+        K = ctx.max_keypoints
+        d_k = torch.zeros((B, K, 2), dtype=torch.int32, device=dev)
+        d_d = torch.zeros((B, K, 72), dtype=torch.int32, device=dev)
+        ctx.set_profiling(24)
+        for r in rows:
+            ctx.set_blur_rows(r)
+            for _ in range(3):
+                ctx.detect_and_compute_dev(d_img.data_ptr(), B, d_k.data_ptr(), d_d.data_ptr())
             ctx.sync()
-            ms = [m["k_blur"] for m in ctx.stage_ms_all()][2:]
-            out.append("%d:%.4f" % (rows, sum(ms) / len(ms)))
-        print("batch %2d  k_blur ms by rows (0 = heuristic)  " % B + "  ".join(out), flush=True)
+            for _ in range(24):
+                ctx.detect_and_compute_dev(d_img.data_ptr(), B, d_k.data_ptr(), d_d.data_ptr())
+            ctx.sync()
+            all_ms = ctx.stage_ms_all()
+            print("blur_rows %4d: k_blur %.4f ms (mean of %d calls), k_detect %.4f" % (r, np.mean([m["k_blur"] for m in all_ms]), len(all_ms), np.mean([m["k_detect"] for m in all_ms])), flush=True)
+
+
+if __name__ == "__main__":
+    main()
