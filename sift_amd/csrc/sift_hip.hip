@@ -147,20 +147,22 @@ std::vector<uint2> build_special_table(int W, const Geometry &g)
 // window in the plane (variant = (row of the window's first row in its group of four) * 4 + column
 // phase), the aligned 4-pixel quads of the window's rows that hold a union pixel; quads with a
 // two-circle pixel first (part A: qa entries after padding, 8 bytes each), then quads that lie in one
-// circle with all four pixels (part U: qu entries, 2 bytes each: (quad * 4 + row in the group) |
-// group of rows << 7 | circle id << 12), then the rest (part B: qb entries, 4 bytes each: group of
-// rows | 4 x circle id << 9 | (quad * 4 + row in the group) << 25).
+// circle with all four pixels: pairs of them in rows 2j, 2j + 1 of a group of four rows -- 16 neighbouring
+// bytes of the row-interleaved plane, one gather for eight pixels -- (part U2: qu2 entries) and single ones
+// (part U: qu entries), 2 bytes each: (quad * 4 + row in the group) | group of rows << 7 | circle id << 12;
+// then the rest (part B: qb entries, 4 bytes each: group of rows | 4 x circle id << 9 | (quad * 4 + row
+// in the group) << 25).
 // All parts are ordered by address in the row-interleaved plane (detect_kernel.h), so consecutive
 // lanes read consecutive 8-byte pieces.
-struct QuadTable { std::vector<uint8_t> bytes; int qa = 0, qu = 0, qb = 0, kmax = 0; };
+struct QuadTable { std::vector<uint8_t> bytes; int qa = 0, qu2 = 0, qu = 0, qb = 0, kmax = 0; };
 QuadTable build_quad_table(int W, const Geometry &g)
 {
     int c1[MAXWIN][MAXWIN], c2[MAXWIN][MAXWIN];
     if (!circle_ids(g, c1, c2)) return QuadTable{};
     const int WS = g.window, QR = (WS + 2) / 4 + 1;     // aligned quads that cover a window row at any phase: 19 / 21
     struct Quad { int y, q, a[4], b[4]; };          // y = window row + row phase: row from the base group's first row
-    std::vector<Quad> A[16], U[16], B[16];
-    size_t na = 0, nu = SIZE_MAX;
+    std::vector<Quad> A[16], U2[16], U[16], B[16];
+    size_t na = 0, nu = SIZE_MAX, nu2 = SIZE_MAX;
     for (int v = 0; v < 16; v++) {
         const int ph = v & 3, yph = v >> 2;
         for (int y = 0; y < WS; y++)
@@ -181,17 +183,47 @@ QuadTable build_quad_table(int W, const Geometry &g)
                 else if (any) B[v].push_back(e);
             }
         na = std::max(na, A[v].size());
-        nu = std::min(nu, U[v].size());
     }
     // bytes from the base: (group of rows) * W * 8 + quad * 32 + (row in the group) * 8
     auto low = [](const Quad &e) { return (e.q * 4 + (e.y & 3)) * 8; };
     auto before = [&](const Quad &l, const Quad &r) { return (l.y >> 2) != (r.y >> 2) ? (l.y >> 2) < (r.y >> 2) : low(l) < low(r); };
     QuadTable t;
     t.qa = (int)((na + 63) / 64 * 64);
-    t.qu = (int)(nu / 64 * 64);                     // whole steps only: the other one-circle quads go to part B
-    size_t nb = 0;
+    // one-circle quads: the upper quad of a pair in rows (2j, 2j + 1) of a group goes to U2, its partner is dropped
+    // from U (it travels with the upper one); whole steps only: what is left of the pairs is split up again and what
+    // is left of the single quads goes to part B
     for (int v = 0; v < 16; v++) {
         std::sort(U[v].begin(), U[v].end(), before);
+        std::vector<Quad> single;
+        std::vector<char> taken(U[v].size(), 0);
+        for (size_t i = 0; i < U[v].size(); i++) {
+            if (taken[i]) continue;
+            const Quad &e = U[v][i];
+            size_t j = U[v].size();
+            if ((e.y & 1) == 0)
+                for (size_t k = i + 1; k < U[v].size(); k++)
+                    if (!taken[k] && U[v][k].y == e.y + 1 && U[v][k].q == e.q && U[v][k].a[0] == e.a[0]) { j = k; break; }
+            if (j < U[v].size()) { taken[j] = 1; U2[v].push_back(e); }
+            else single.push_back(e);
+        }
+        U[v] = single;
+        nu2 = std::min(nu2, U2[v].size());
+    }
+    t.qu2 = (int)(nu2 / 64 * 64);
+    for (int v = 0; v < 16; v++) {
+        for (size_t i = (size_t)t.qu2; i < U2[v].size(); i++) {       // pairs beyond the whole steps: two single quads again
+            Quad lower = U2[v][i];
+            lower.y += 1;
+            U[v].push_back(U2[v][i]);
+            U[v].push_back(lower);
+        }
+        U2[v].resize((size_t)t.qu2);
+        std::sort(U[v].begin(), U[v].end(), before);
+        nu = std::min(nu, U[v].size());
+    }
+    t.qu = (int)(nu / 64 * 64);
+    size_t nb = 0;
+    for (int v = 0; v < 16; v++) {
         B[v].insert(B[v].end(), U[v].begin() + t.qu, U[v].end());
         U[v].resize((size_t)t.qu);
         nb = std::max(nb, B[v].size());
@@ -219,6 +251,11 @@ QuadTable build_quad_table(int W, const Geometry &g)
             }
             put32(lo);
             put32(hi);
+        }
+        for (size_t i = 0; i < U2[ph].size(); i++) {
+            const Quad &e = U2[ph][i];
+            k[i % 32][e.a[0]] += 8;
+            put16((uint32_t)(e.q * 4 + (e.y & 3)) | (uint32_t)(e.y >> 2) << 7 | (uint32_t)e.a[0] << 12);
         }
         for (size_t i = 0; i < U[ph].size(); i++) {
             const Quad &e = U[ph][i];
@@ -272,6 +309,7 @@ struct sift_hip_ctx {
     size_t bgr_cap = 0;
     uint2 *d_tab = nullptr;
     uint32_t *d_qtab = nullptr;           // quad table (build_quad_table)
+    int qu2 = 0;                          // its part U2 (pairs of one-circle quads)
     uint2 *d_spec = nullptr;              // orientation corrections of the geometry (build_special_table)
     int nspec = 0, radius = 35, qrow4 = 76; // window radius and bytes^-1: 4 x aligned quads per window row (describe kernel)
     uint32_t *d_gate = nullptr;           // k_grad_pairs' flag: which of the two describe kernels of a stand-alone call runs
@@ -468,27 +506,28 @@ int run_describe(sift_hip_ctx *c, const void *d_grad, int nframes, const sift::k
     // geometries with orientation corrections (Cam1) run the table-driven variants with the correction step
     if (c->nspec) {
         if ((int)grid.x == c->max_kp)
-            hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false, 0, 0, 0, true>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                               d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec, c->Wl);
+            hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false, 0, 0, 0, 0, true>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
+                               d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu2, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec, c->Wl);
         else
-            hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true, 0, 0, 0, true>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                               d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec, c->Wl);
+            hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true, 0, 0, 0, 0, true>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
+                               d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu2, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec, c->Wl);
         HIP_TRY(hipGetLastError());
         return SIFT_HIP_OK;
     }
-    // the reference's masks give 5 + 9 + 2 steps of 64 quads: straight-line variant
-    if (GFMT == sift::GRAD_PACKED16 && (int)grid.x == c->max_kp && c->qa == 5 * 64 && c->qu == 9 * 64 && c->qb == 2 * 64)
-        hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false, 5, 9, 2>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec, c->Wl);
+    // the reference's masks give 5 + 4 + 1 + 2 steps of 64 entries: straight-line variant
+    const bool ref_steps = c->qa == 5 * 64 && c->qu2 == 4 * 64 && c->qu == 64 && c->qb == 2 * 64;
+    if (GFMT == sift::GRAD_PACKED16 && (int)grid.x == c->max_kp && ref_steps)
+        hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false, 5, 4, 1, 2>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu2, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec, c->Wl);
     else if ((int)grid.x == c->max_kp)
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, false>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec, c->Wl);
-    else if (GFMT == sift::GRAD_PACKED16 && c->qa == 5 * 64 && c->qu == 9 * 64 && c->qb == 2 * 64)
-        hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true, 5, 9, 2>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec, c->Wl);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu2, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec, c->Wl);
+    else if (GFMT == sift::GRAD_PACKED16 && ref_steps)
+        hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true, 5, 4, 1, 2>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu2, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec, c->Wl);
     else
         hipLaunchKernelGGL((sift::k_describe<GFMT, MODE, true>), grid, dim3(64), 0, s, d_grad, d_kps, ori_in, ori_out,
-                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec, c->Wl);
+                           d_desc, c->d_tab, c->n2, c->n2pad, c->ntab, c->quad_sweep ? c->d_qtab : nullptr, c->qa, c->qu2, c->qu, c->qb, tot, c->W, c->H, c->max_kp, gate, gate_want, c->radius, c->qrow4, c->d_spec, c->nspec, c->Wl);
     HIP_TRY(hipGetLastError());
     return SIFT_HIP_OK;
 }
@@ -643,7 +682,7 @@ int sift_hip_create_geometry(sift_hip_ctx **out, int device, int width, int heig
     A((void **)&c->d_ori, B * (size_t)max_keypoints);
     A((void **)&c->d_tab, tab.size() * sizeof(uint2));
     c->ntab = (int)tab.size(); c->n2 = wt.n2; c->n2pad = wt.n2pad;
-    c->qa = qt.qa; c->qu = qt.qu; c->qb = qt.qb;
+    c->qa = qt.qa; c->qu2 = qt.qu2; c->qu = qt.qu; c->qb = qt.qb;
     c->radius = geo.radius; c->qrow4 = ((geo.window + 2) / 4 + 1) * 4; c->nspec = (int)spec.size();
     A((void **)&c->d_spec, std::max<size_t>(1, spec.size()) * sizeof(uint2));
     if (e == hipSuccess && !spec.empty()) e = hipMemcpy(c->d_spec, spec.data(), spec.size() * sizeof(uint2), hipMemcpyHostToDevice);
@@ -1355,7 +1394,7 @@ int sift_hip_detect_and_compute_static(int device, const uint8_t *d_imgs, int nf
         c->d_tab = (uint2 *)st.base;
         c->d_qtab = (uint32_t *)(st.base + qoff);
         c->ntab = (int)wt.e.size(); c->n2 = wt.n2; c->n2pad = wt.n2pad;
-        c->qa = qt.qa; c->qu = qt.qu; c->qb = qt.qb;
+        c->qa = qt.qa; c->qu2 = qt.qu2; c->qu = qt.qu; c->qb = qt.qb;
         st.table_width = width;
     }
     c->W = width; c->Wl = width; c->H = height; c->S = (width + 63) / 64;
