@@ -73,6 +73,20 @@ namespace sift {
 enum { DESC_FUSED = 0, DESC_ORI_ONLY = 1, DESC_GIVEN_ORI = 2 };
 enum { GRAD_PACKED16 = 0, GRAD_FULL32 = 1 };
 
+// The quad table of one window alignment is 64 records, one per lane: the lane's entries of every step, part A
+// (8 bytes each) first, then U2 and U (2 bytes each), then B (4 bytes each, on a 4-byte boundary), the record
+// padded to a multiple of 16 bytes.  A lane fetches its record with a few 16-byte loads (the reference's masks:
+// 5, 4 + 1 and 2 steps = 64 bytes = four loads; one load per entry costs 0.9 % of the kernel each, measured).
+// In memory the records are interleaved by 16-byte piece -- piece i of lane l at (i * 64 + l) * 16 -- so that a
+// load of the wave reads 1 KB of consecutive bytes.
+struct QuadRecord {
+    int offU2, offU, offB, size;
+    __host__ __device__ constexpr QuadRecord(int na, int nu2, int nu, int nb)
+        : offU2(na * 8), offU(na * 8 + nu2 * 2), offB((na * 8 + (nu2 + nu) * 2 + 3) & ~3), size((((na * 8 + (nu2 + nu) * 2 + 3) & ~3) + nb * 4 + 15) & ~15) {}
+    // byte `ofs` of lane `lane`'s record, from the start of the alignment's table
+    __host__ __device__ static constexpr uint32_t at(uint32_t lane, uint32_t ofs) { return ((ofs >> 4) * 64u + lane) * 16u + (ofs & 15u); }
+};
+
 constexpr int DESC_MAX_MAG_PACKED = 360;     // floor(sqrt(2*255^2)), the largest k_detect can produce
 constexpr int DESC_UNROLL = 4;               // table entries a lane has in flight
 
@@ -365,49 +379,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         quad_pixel(two, even, q.y, e.y >> 16, e.x >> 16);
         quad_pixel(two, odd, q.y, e.y >> 24, e.x >> 17);
     };
-    // tq: this phase's table, qa 8-byte entries (part A), qu2 + qu 2-byte entries (parts U2, U), qb 4-byte entries (part B)
+    // tq: this alignment's table, 64 records (QuadRecord)
+    // generic path: tq = the alignment's table, part = byte offset of the part in a record, t0 = first step of the chunk
     auto chunk_a = [&](auto nu, const char *gq, const char *tq, int t0) {
         constexpr int N = decltype(nu)::value;
         uint2 e[N], q[N];
-        const uint32_t tb = (uint32_t)(t0 + lane) * 8u;
 #pragma unroll
-        for (int u = 0; u < N; u++) e[u] = *reinterpret_cast<const uint2 *>(tq + tb + (uint32_t)u * 512u);
+        for (int u = 0; u < N; u++) e[u] = *reinterpret_cast<const uint2 *>(tq + QuadRecord::at((uint32_t)lane, (uint32_t)(t0 + u) * 8u));
 #pragma unroll
         for (int u = 0; u < N; u++) q[u] = *reinterpret_cast<const uint2 *>(gq + (e[u].x & 0xffffffu));
 #pragma unroll
         for (int u = 0; u < N; u++) a_pixels(e[u], q[u]);
     };
-    auto chunk_b = [&](auto nu, const char *gq, const char *tb0, int t0) {
+    auto chunk_b = [&](auto nu, const char *gq, const char *tq, int part, int t0) {
         constexpr int N = decltype(nu)::value;
         uint32_t e[N];
         uint2 q[N];
-        const uint32_t tb = (uint32_t)(t0 + lane) * 4u;
 #pragma unroll
-        for (int u = 0; u < N; u++) e[u] = *reinterpret_cast<const uint32_t *>(tb0 + tb + (uint32_t)u * 256u);
+        for (int u = 0; u < N; u++) e[u] = *reinterpret_cast<const uint32_t *>(tq + QuadRecord::at((uint32_t)lane, (uint32_t)part + (uint32_t)(t0 + u) * 4u));
 #pragma unroll
         for (int u = 0; u < N; u++) q[u] = *reinterpret_cast<const uint2 *>(gq + b_offset(e[u]));
 #pragma unroll
         for (int u = 0; u < N; u++) b_pixels(e[u], q[u]);
     };
-    auto chunk_u2 = [&](auto nu, const char *gq, const char *tu0, int t0) {
+    auto chunk_u2 = [&](auto nu, const char *gq, const char *tq, int part, int t0) {
         constexpr int N = decltype(nu)::value;
         uint32_t e[N];
         uint4 q[N];
-        const uint32_t tb = (uint32_t)(t0 + lane) * 2u;
 #pragma unroll
-        for (int u = 0; u < N; u++) e[u] = *reinterpret_cast<const uint16_t *>(tu0 + tb + (uint32_t)u * 128u);
+        for (int u = 0; u < N; u++) e[u] = *reinterpret_cast<const uint16_t *>(tq + QuadRecord::at((uint32_t)lane, (uint32_t)part + (uint32_t)(t0 + u) * 2u));
 #pragma unroll
         for (int u = 0; u < N; u++) q[u] = *reinterpret_cast<const uint4 *>(gq + u_offset(e[u]));
 #pragma unroll
         for (int u = 0; u < N; u++) u2_pixels(e[u], q[u]);
     };
-    auto chunk_u = [&](auto nu, const char *gq, const char *tu0, int t0) {
+    auto chunk_u = [&](auto nu, const char *gq, const char *tq, int part, int t0) {
         constexpr int N = decltype(nu)::value;
         uint32_t e[N];
         uint2 q[N];
-        const uint32_t tb = (uint32_t)(t0 + lane) * 2u;
 #pragma unroll
-        for (int u = 0; u < N; u++) e[u] = *reinterpret_cast<const uint16_t *>(tu0 + tb + (uint32_t)u * 128u);
+        for (int u = 0; u < N; u++) e[u] = *reinterpret_cast<const uint16_t *>(tq + QuadRecord::at((uint32_t)lane, (uint32_t)part + (uint32_t)(t0 + u) * 2u));
 #pragma unroll
         for (int u = 0; u < N; u++) q[u] = *reinterpret_cast<const uint2 *>(gq + u_offset(e[u]));
 #pragma unroll
@@ -420,17 +431,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         uint2 ea[MA], qa_[MA], qu_[MU], qb_[MB];
         uint4 qu2_[MU2];
         uint32_t eu2[MU2], eu[MU], eb[MB];
-        const char *tu20 = tq + (size_t)NA * 512u;
-        const char *tu0 = tu20 + (size_t)NU2 * 128u;
-        const char *tb0 = tu0 + (size_t)NU * 128u;
+        // the lane's record in 16-byte loads; the entries are dwords / halves of dwords of it
+        constexpr QuadRecord R(NA, NU2, NU, NB);
+        constexpr int ND = R.size > 0 ? R.size / 4 : 4;                  // (instantiated, never run, for the table-driven variants)
+        uint32_t rec[ND];
 #pragma unroll
-        for (int u = 0; u < NA; u++) ea[u] = *reinterpret_cast<const uint2 *>(tq + (uint32_t)lane * 8u + (uint32_t)u * 512u);
+        for (int i = 0; i < ND / 4; i++) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(tq + QuadRecord::at((uint32_t)lane, (uint32_t)i * 16u));
+            rec[4 * i] = v.x; rec[4 * i + 1] = v.y; rec[4 * i + 2] = v.z; rec[4 * i + 3] = v.w;
+        }
+        auto half = [&](int byteofs) { return (byteofs & 2) ? rec[byteofs >> 2] >> 16 : rec[byteofs >> 2]; };   // the fields' masks drop a low half's upper bits
 #pragma unroll
-        for (int u = 0; u < NU2; u++) eu2[u] = *reinterpret_cast<const uint16_t *>(tu20 + (uint32_t)lane * 2u + (uint32_t)u * 128u);
+        for (int u = 0; u < NA; u++) ea[u] = make_uint2(rec[2 * u], rec[2 * u + 1]);
 #pragma unroll
-        for (int u = 0; u < NU; u++) eu[u] = *reinterpret_cast<const uint16_t *>(tu0 + (uint32_t)lane * 2u + (uint32_t)u * 128u);
+        for (int u = 0; u < NU2; u++) eu2[u] = half(R.offU2 + 2 * u);
 #pragma unroll
-        for (int u = 0; u < NB; u++) eb[u] = *reinterpret_cast<const uint32_t *>(tb0 + (uint32_t)lane * 4u + (uint32_t)u * 256u);
+        for (int u = 0; u < NU; u++) eu[u] = half(R.offU + 2 * u);
+#pragma unroll
+        for (int u = 0; u < NB; u++) eb[u] = rec[R.offB / 4 + u];
 #pragma unroll
         for (int u = 0; u < NA; u++) qa_[u] = *reinterpret_cast<const uint2 *>(gq + (ea[u].x & 0xffffffu));
 #pragma unroll
@@ -449,21 +467,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         for (int u = 0; u < NB; u++) b_pixels(eb[u], qb_[u]);
     };
     auto quad_loops = [&](const char *gq, const char *tq) {
+        const QuadRecord R(qa >> 6, qu2 >> 6, qu >> 6, qb >> 6);
+        const int na = qa >> 6, nu2 = qu2 >> 6, nu = qu >> 6, nb = qb >> 6;
         int t0 = 0;
-        for (; t0 + 64 * U <= qa; t0 += 64 * U) chunk_a(std::integral_constant<int, U>{}, gq, tq, t0);
-        for (; t0 < qa; t0 += 64) chunk_a(std::integral_constant<int, 1>{}, gq, tq, t0);
-        const char *tu20 = tq + (size_t)qa * 8u;
+        for (; t0 + U <= na; t0 += U) chunk_a(std::integral_constant<int, U>{}, gq, tq, t0);
+        for (; t0 < na; t0++) chunk_a(std::integral_constant<int, 1>{}, gq, tq, t0);
         t0 = 0;
-        for (; t0 + 64 * 2 <= qu2; t0 += 64 * 2) chunk_u2(std::integral_constant<int, 2>{}, gq, tu20, t0);
-        for (; t0 < qu2; t0 += 64) chunk_u2(std::integral_constant<int, 1>{}, gq, tu20, t0);
-        const char *tu0 = tu20 + (size_t)qu2 * 2u;
+        for (; t0 + 2 <= nu2; t0 += 2) chunk_u2(std::integral_constant<int, 2>{}, gq, tq, R.offU2, t0);
+        for (; t0 < nu2; t0++) chunk_u2(std::integral_constant<int, 1>{}, gq, tq, R.offU2, t0);
         t0 = 0;
-        for (; t0 + 64 * U <= qu; t0 += 64 * U) chunk_u(std::integral_constant<int, U>{}, gq, tu0, t0);
-        for (; t0 < qu; t0 += 64) chunk_u(std::integral_constant<int, 1>{}, gq, tu0, t0);
-        const char *tb0 = tu0 + (size_t)qu * 2u;
+        for (; t0 + U <= nu; t0 += U) chunk_u(std::integral_constant<int, U>{}, gq, tq, R.offU, t0);
+        for (; t0 < nu; t0++) chunk_u(std::integral_constant<int, 1>{}, gq, tq, R.offU, t0);
         t0 = 0;
-        for (; t0 + 64 * U <= qb; t0 += 64 * U) chunk_b(std::integral_constant<int, U>{}, gq, tb0, t0);
-        for (; t0 < qb; t0 += 64) chunk_b(std::integral_constant<int, 1>{}, gq, tb0, t0);
+        for (; t0 + U <= nb; t0 += U) chunk_b(std::integral_constant<int, U>{}, gq, tq, R.offB, t0);
+        for (; t0 < nb; t0++) chunk_b(std::integral_constant<int, 1>{}, gq, tq, R.offB, t0);
     };
 
     // the window is rows py-35..py+35 at columns px-35..px+35 of a linearly addressed plane
@@ -473,7 +490,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         const int xph = x0 & 3, yph = y0 & 3;        // one table per alignment of the window in the plane
         if (qtab && x0 - xph >= 0 && x0 - xph + qrow4 <= W && px + radius < Wl && y0 >= 0 && py + radius < H) {
             const char *gq = gplane + gradp_quad_word(y0 - yph, (x0 - xph) >> 2, W4) * 2;
-            const char *tq = reinterpret_cast<const char *>(qtab) + (size_t)(yph * 4 + xph) * ((size_t)qa * 8u + (size_t)(qu2 + qu) * 2u + (size_t)qb * 4u);
+            const char *tq = reinterpret_cast<const char *>(qtab) + (size_t)(yph * 4 + xph) * 64u * (size_t)QuadRecord(qa >> 6, qu2 >> 6, qu >> 6, qb >> 6).size;
             if constexpr (NA + NU2 + NU + NB > 0) quad_static(gq, tq);
             else quad_loops(gq, tq);
         } else {

@@ -153,7 +153,8 @@ std::vector<uint2> build_special_table(int W, const Geometry &g)
 // then the rest (part B: qb entries, 4 bytes each: group of rows | 4 x circle id << 9 | (quad * 4 + row
 // in the group) << 25).
 // All parts are ordered by address in the row-interleaved plane (detect_kernel.h), so consecutive
-// lanes read consecutive 8-byte pieces.
+// lanes read consecutive pieces.  The entries of a window alignment are stored as 64 records, one per lane
+// (sift::QuadRecord), which a lane fetches with a few 16-byte loads.
 struct QuadTable { std::vector<uint8_t> bytes; int qa = 0, qu2 = 0, qu = 0, qb = 0, kmax = 0; };
 QuadTable build_quad_table(int W, const Geometry &g)
 {
@@ -230,13 +231,21 @@ QuadTable build_quad_table(int W, const Geometry &g)
     }
     t.qb = (int)((nb + 63) / 64 * 64);
     const Quad nop = {0, 0, {10, 10, 10, 10}, {10, 10, 10, 10}};   // offset 0, every pixel -> spare rows
-    auto put16 = [&](uint32_t w) { t.bytes.push_back((uint8_t)w); t.bytes.push_back((uint8_t)(w >> 8)); };
-    auto put32 = [&](uint32_t w) { put16(w); put16(w >> 16); };
+    // a phase = 64 records, one per lane, interleaved by 16-byte piece (sift::QuadRecord): entry i of a part belongs to
+    // lane i % 64, step i / 64
+    const sift::QuadRecord R(t.qa / 64, t.qu2 / 64, t.qu / 64, t.qb / 64);
+    t.bytes.assign((size_t)16 * 64 * (size_t)R.size, 0);
+    uint8_t *phase = nullptr;
+    auto put = [&](int part_off, int entry_bytes, size_t i, uint32_t w0, uint32_t w1 = 0) {
+        uint8_t *d = phase + sift::QuadRecord::at((uint32_t)(i % 64), (uint32_t)part_off + (uint32_t)(i / 64) * (uint32_t)entry_bytes);   // an entry never straddles a 16-byte piece
+        for (int b = 0; b < entry_bytes; b++) d[b] = (uint8_t)((b < 4 ? w0 >> (8 * b) : w1 >> (8 * (b - 4))));
+    };
     for (int ph = 0; ph < 16; ph++) {
         std::sort(A[ph].begin(), A[ph].end(), before);
         std::sort(B[ph].begin(), B[ph].end(), before);
         A[ph].resize((size_t)t.qa, nop);
         B[ph].resize((size_t)t.qb, nop);
+        phase = t.bytes.data() + (size_t)ph * 64 * (size_t)R.size;
         // pixels per (LDS column, circle | overlap) of this phase; entry i falls to column i % 32
         int k[32][10];
         memset(k, 0, sizeof k);
@@ -249,18 +258,17 @@ QuadTable build_quad_table(int W, const Geometry &g)
                 hi |= (uint32_t)(e.a[p] | e.b[p] << 4) << (8 * p);
                 if (e.b[p] == 10) lo |= 1u << (24 + p);            // notov: the third add goes to the spare rows
             }
-            put32(lo);
-            put32(hi);
+            put(0, 8, i, lo, hi);
         }
         for (size_t i = 0; i < U2[ph].size(); i++) {
             const Quad &e = U2[ph][i];
             k[i % 32][e.a[0]] += 8;
-            put16((uint32_t)(e.q * 4 + (e.y & 3)) | (uint32_t)(e.y >> 2) << 7 | (uint32_t)e.a[0] << 12);
+            put(R.offU2, 2, i, (uint32_t)(e.q * 4 + (e.y & 3)) | (uint32_t)(e.y >> 2) << 7 | (uint32_t)e.a[0] << 12);
         }
         for (size_t i = 0; i < U[ph].size(); i++) {
             const Quad &e = U[ph][i];
             k[i % 32][e.a[0]] += 4;
-            put16((uint32_t)(e.q * 4 + (e.y & 3)) | (uint32_t)(e.y >> 2) << 7 | (uint32_t)e.a[0] << 12);
+            put(R.offU, 2, i, (uint32_t)(e.q * 4 + (e.y & 3)) | (uint32_t)(e.y >> 2) << 7 | (uint32_t)e.a[0] << 12);
         }
         for (size_t i = 0; i < B[ph].size(); i++) {
             const Quad &e = B[ph][i];
@@ -269,7 +277,7 @@ QuadTable build_quad_table(int W, const Geometry &g)
                 if (e.a[p] < 9) k[i % 32][e.a[p]]++;
                 w |= (uint32_t)e.a[p] << (9 + 4 * p);
             }
-            put32(w);
+            put(R.offB, 4, i, w);
         }
         for (int c = 0; c < 32; c++)
             for (int n = 0; n < 10; n++) t.kmax = std::max(t.kmax, k[c][n]);
