@@ -206,7 +206,9 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
     // wraps to 4 GB) and rows above / below the image get zeros from the bounds check, which is what
     // "outside the image reads 0" needs -- no masks, no address arithmetic in the loop.
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const uint32_t goff = (uint32_t)g * 16u, hoff = (uint32_t)gh * 16u;
+    // only lanes 0 and 63 use their halo group: the others ask for an offset beyond the row, which the bounds check
+    // answers with zeros without a trip to the cache
+    const uint32_t goff = (uint32_t)g * 16u, hoff = (lane == 0 || lane == 63) ? (uint32_t)gh * 16u : 0xfffffff0u;
     auto load_row = [&](int r, uint4 &Q, uint4 &Qh) {
         const bool in = r >= 0 && r < H;                                         // wave-uniform
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
