@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_grad_pairs(const uint4 *__restrict__ gr
 // SPEC: the geometry has orientation corrections (spec, nspec); the reference's geometry has none, and its
 // kernels carry no code for them (with it the straight-line variant no longer fits its 80 registers)
 template <int GFMT, int MODE, bool LOOP = false, int NA = 0, int NU2 = 0, int NU = 0, int NB = 0, bool SPEC = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_describe(const void *__restrict__ gradv, const kp_t *__restrict__ kps,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GFMT == 0 ? 6 : 4, 8))) void k_describe(const void *__restrict__ gradv, const kp_t *__restrict__ kps,
                                                  const uint8_t *__restrict__ ori_in, uint8_t *__restrict__ ori_out,
                                                  uint32_t *__restrict__ desc, const uint2 *__restrict__ tab,
                                                  int n2, int n2pad, int ntab, const void *__restrict__ qtab,
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     constexpr int LROWS = PACK ? 48 : 80;        // + circle id 10: spare rows of the quad sweep (never read)
     constexpr int U = DESC_UNROLL;
     __shared__ __align__(16) uint32_t hist[LROWS][32];
-    __shared__ uint32_t fin[80];
+    __shared__ __align__(8) uint32_t fin[80];
     __shared__ uint32_t corr[8];                 // orientation corrections of the geometry (spec), per direction code
 
     const int lane = threadIdx.x;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         // 256 bytes against 13 per 1024 for ds_write_b128).  Nothing else in this kernel uses M0.
         const uint32_t hist_lds = (uint32_t)(uintptr_t)&hist[0][0];   // low half of the flat address = LDS offset
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(hist_lds));   // an M0 write needs one wait state before an add-TID access
-        static_for<0, LROWS * 32 * 4 / 256>([&](auto i) {
+        static_for<0, ROWS * 32 * 4 / 256>([&](auto i) {                 // the spare rows are never read: they need no clearing
             asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(0u), "i"((int)decltype(i)::value * 256) : "memory");
         });
         if (SPEC && lane < 8) corr[lane] = 0u;
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 lo += dpp_mov<0x111>(lo); hi += dpp_mov<0x111>(hi);    // row_shr:1
                 lo += dpp_mov<0x112>(lo); hi += dpp_mov<0x112>(hi);    // row_shr:2
                 lo += dpp_mov<0x114>(lo); hi += dpp_mov<0x114>(hi);    // row_shr:4
-                if (cg == 7) { fin[row * 2] = lo; fin[row * 2 + 1] = hi; }
+                if (cg == 7) *reinterpret_cast<uint2 *>(&fin[row * 2]) = make_uint2(lo, hi);
             } else {
                 uint32_t s = q.x + q.y + q.z + q.w;
                 s += dpp_mov<0x111>(s);
