@@ -140,12 +140,20 @@ int sift_hip_descriptor(sift_hip_ctx *ctx, const sift_grad *grad, const sift_key
 int sift_hip_select_top(sift_hip_ctx *ctx, const sift_keypoint *kps, int nfinal, sift_keypoint *final_kps,
                         uint32_t *index, uint32_t *nvalid);
 
-/* The image loop of main.cpp:37-210 as one call: frame f of `nframes` goes to
- * context f % nctx (one context per GPU), outputs land in the caller's
- * per-frame slots kps[f*max_keypoints], desc[f*max_keypoints*72].  Frames are
- * independent: no exchange between contexts. */
+/* The image loop of main.cpp:37-210 as one call over one context per GPU: context i takes the contiguous
+ * range of frames sift_hip_batch_range gives it (ceil(nframes / nctx) frames each, the last ranges
+ * shorter or empty), on a host thread of its own; outputs land in the caller's per-frame slots
+ * kps[f*max_keypoints], desc[f*max_keypoints*72].  Frames are independent: no exchange between
+ * contexts.  Inside a context the frames travel in chunks of max_batch / 2, double buffered on the
+ * context's own copy streams (created by its first batch call, kept until sift_hip_destroy: a later
+ * call creates no stream, event or device buffer); frames that are neighbours in host memory go up
+ * as one copy, a chunk's results come back as one copy per array. */
 int sift_hip_batch(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *imgs, int nframes,
                    sift_keypoint *kps, uint32_t *desc, int contrastTh);
+
+/* The partition rule of sift_hip_batch[_top] (needs no device): context i of nctx
+ * owns frames [*first, *last) of nframes. */
+int sift_hip_batch_range(int nframes, int nctx, int i, int *first, int *last);
 
 /* The same loop with the post-processing of main.cpp:82-130 on the device: per frame only the
  * nfinal strongest keypoints (descending contrast, ties in slot order), their slots, their
@@ -274,6 +282,10 @@ int sift_hip_next_octave(sift_hip_ctx *ctx, int frame, int plane, uint8_t *dst);
  * before the border filter (kpMap2, :693). */
 int sift_hip_debug_planes(sift_hip_ctx *ctx, int frame, uint8_t *g1, uint8_t *g2, uint8_t *g3, uint16_t *cand,
                           int32_t *eratio, uint16_t *surv);
+
+/* How many streams (what = 0), events (1) and device buffers (2) the library has created in this
+ * process so far (-1 for another `what`).  Test hook: two readings around a call show what it created. */
+long sift_hip_debug_created(int what);
 
 /* Per-kernel HIP-event timing.  sift_hip_set_profiling(ctx, nslots) keeps a ring
  * of the last `nslots` calls (0 switches profiling off); every *_dev / host

@@ -28,7 +28,7 @@ EXPORTS = (
     "sift_hip_host_alloc", "sift_hip_host_free",
     "sift_hip_detect_and_compute", "sift_hip_detect", "sift_hip_main_orientation", "sift_hip_descriptor",
     "sift_hip_select_top", "sift_hip_select_top_dev", "sift_hip_gray_from_bgr", "sift_hip_gray_from_bgr_dev",
-    "sift_hip_match", "sift_hip_match_dev", "sift_hip_batch", "sift_hip_batch_top", "sift_hip_detect_and_compute_dev", "sift_hip_detect_dev",
+    "sift_hip_match", "sift_hip_match_dev", "sift_hip_batch", "sift_hip_batch_top", "sift_hip_batch_range", "sift_hip_debug_created", "sift_hip_detect_and_compute_dev", "sift_hip_detect_dev",
     "sift_hip_main_orientation_dev", "sift_hip_descriptor_dev", "sift_hip_sync", "sift_hip_debug_planes",
     "sift_hip_next_octave", "sift_hip_next_octave_dev",
     "sift_hip_set_profiling", "sift_hip_stage_ms", "sift_hip_stage_name", "sift_hip_set_blur_rows", "sift_hip_set_blur_mfma", "sift_hip_set_detect_rows", "sift_hip_set_detect_queue", "sift_hip_detect_and_compute_static", "sift_hip_static_scratch_needed", "sift_hip_set_graph_frames", "sift_hip_set_quad_sweep",
@@ -83,6 +83,9 @@ def load_library():
     lib.sift_hip_descriptor.argtypes = [vp, vp, vp, vp, vp]
     lib.sift_hip_batch.argtypes = [C.POINTER(vp), i32, C.POINTER(vp), i32, vp, vp, i32]
     lib.sift_hip_batch_top.argtypes = [C.POINTER(vp), i32, C.POINTER(vp), i32, i32, vp, vp, vp, vp, i32]
+    lib.sift_hip_batch_range.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.sift_hip_debug_created.argtypes = [i32]
+    lib.sift_hip_debug_created.restype = C.c_long
     lib.sift_hip_detect_and_compute_dev.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp]
     lib.sift_hip_detect_dev.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp]
     lib.sift_hip_main_orientation_dev.argtypes = [vp, vp, i32, vp, vp, vp]

@@ -15,6 +15,7 @@
 #include <vector>
 #include <thread>
 #include <mutex>
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 
@@ -52,6 +53,13 @@ int fail(int code, const char *what, hipError_t e = hipSuccess)
         hipError_t e_ = (expr);                                       \
         if (e_ != hipSuccess) return fail(SIFT_HIP_EHIP, #expr, e_); \
     } while (0)
+
+// Everything the library creates on a device goes through these three, which count: a caller (and
+// tests/test_parity_gpu.py) can check through sift_hip_debug_created that a steady-state call creates nothing.
+std::atomic<long> g_created[3];           // streams, events, device allocations since the library was loaded
+hipError_t make_stream(hipStream_t *s) { g_created[0]++; return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+hipError_t make_event(hipEvent_t *e, unsigned flags) { g_created[1]++; return hipEventCreateWithFlags(e, flags); }
+template <class T> hipError_t dev_alloc(T **p, size_t bytes) { g_created[2]++; return hipMalloc((void **)p, bytes); }
 
 enum { ST_BLUR = 0, ST_DETECT, ST_CULL, ST_EMIT, ST_DESCRIBE };
 const char *const kStageNames[SIFT_HIP_NSTAGES] = {"k_blur", "k_detect", "k_cull", "k_emit", "k_describe"};
@@ -315,6 +323,11 @@ struct sift_hip_ctx {
     size_t match_cap = 0;
     uint8_t *d_bgr = nullptr;             // staging of sift_hip_gray_from_bgr (lazily allocated)
     size_t bgr_cap = 0;
+    uint8_t *d_oct = nullptr;             // staging of sift_hip_next_octave (lazily allocated, one frame)
+    // sift_hip_batch[_top]: the two copy streams and the hand-over events of the chunks in flight; made by the
+    // first batch call on this context and kept (ensure_batch_streams)
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t in_done[2] = {}, k_done[2] = {}, out_done[2] = {};
     uint2 *d_tab = nullptr;
     uint32_t *d_qtab = nullptr;           // quad table (build_quad_table)
     int qu2 = 0;                          // its part U2 (pairs of one-circle quads)
@@ -581,15 +594,27 @@ int check_ctx(const sift_hip_ctx *c)
 int ensure_select(sift_hip_ctx *c)
 {
     const size_t n = (size_t)std::min(c->max_kp, (int)sift::SEL_MAX_FINAL);
-    if (!c->d_final) HIP_TRY(hipMalloc(&c->d_final, n * sizeof(sift::kp_t)));
-    if (!c->d_findex) HIP_TRY(hipMalloc(&c->d_findex, n * 4));
-    if (!c->d_nvalid) HIP_TRY(hipMalloc(&c->d_nvalid, 4));
+    if (!c->d_final) HIP_TRY(dev_alloc(&c->d_final, n * sizeof(sift::kp_t)));
+    if (!c->d_findex) HIP_TRY(dev_alloc(&c->d_findex, n * 4));
+    if (!c->d_nvalid) HIP_TRY(dev_alloc(&c->d_nvalid, 4));
+    return SIFT_HIP_OK;
+}
+
+int ensure_batch_streams(sift_hip_ctx *c)
+{
+    if (!c->s_in) HIP_TRY(make_stream(&c->s_in));
+    if (!c->s_out) HIP_TRY(make_stream(&c->s_out));
+    for (int i = 0; i < 2; i++) {
+        if (!c->in_done[i]) HIP_TRY(make_event(&c->in_done[i], hipEventDisableTiming));
+        if (!c->k_done[i]) HIP_TRY(make_event(&c->k_done[i], hipEventDisableTiming));
+        if (!c->out_done[i]) HIP_TRY(make_event(&c->out_done[i], hipEventDisableTiming));
+    }
     return SIFT_HIP_OK;
 }
 
 int ensure_gradfull(sift_hip_ctx *c)
 {
-    if (!c->d_gradfull) HIP_TRY(hipMalloc(&c->d_gradfull, c->npix * sizeof(uint32_t)));
+    if (!c->d_gradfull) HIP_TRY(dev_alloc(&c->d_gradfull, c->npix * sizeof(uint32_t)));
     return SIFT_HIP_OK;
 }
 
@@ -672,8 +697,8 @@ int sift_hip_create_geometry(sift_hip_ctx **out, int device, int width, int heig
     c->npix = (size_t)width * height;
     const size_t B = (size_t)max_batch, np = c->npix, HS = (size_t)height * c->S;
     hipError_t e = hipSuccess;
-    auto A = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    auto A = [&](void **p, size_t bytes) { if (e == hipSuccess) e = dev_alloc(p, bytes); };
+    if (e == hipSuccess) e = make_stream(&c->stream);
     A((void **)&c->d_img, B * np);
     if (e == hipSuccess && logical_width != width) e = hipMemset(c->d_img, 0, B * np);   // the padding columns stay zero
     A((void **)&c->d_pyr, B * np * 4);
@@ -712,12 +737,15 @@ void sift_hip_destroy(sift_hip_ctx *c)
     DevGuard g(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_img, c->d_pyr, c->d_cand, c->d_surv, c->d_key, c->d_rowcount, c->d_rowbase, c->d_gradp,
-                    c->d_gradfull, c->d_final, c->d_findex, c->d_nvalid, c->d_tfinal, c->d_tindex, c->d_tdesc, c->d_tnvalid, c->d_bgr, c->d_match, c->d_kps, c->d_desc, c->d_total, c->d_total_ctx, c->d_ori, c->d_tab, c->d_qtab, c->d_gate, c->d_spec};
+                    c->d_gradfull, c->d_final, c->d_findex, c->d_nvalid, c->d_tfinal, c->d_tindex, c->d_tdesc, c->d_tnvalid, c->d_bgr, c->d_oct, c->d_match, c->d_kps, c->d_desc, c->d_total, c->d_total_ctx, c->d_ori, c->d_tab, c->d_qtab, c->d_gate, c->d_spec};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &ps : c->prof)
         for (int i = 0; i < SIFT_HIP_NSTAGES; i++)
             for (int k = 0; k < 2; k++) if (ps.ev[i][k]) hipEventDestroy(ps.ev[i][k]);
     if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
+    for (hipStream_t bs : {c->s_in, c->s_out}) if (bs) { (void)hipStreamSynchronize(bs); (void)hipStreamDestroy(bs); }
+    for (int i = 0; i < 2; i++)
+        for (hipEvent_t ev : {c->in_done[i], c->k_done[i], c->out_done[i]}) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -745,7 +773,7 @@ int sift_hip_set_profiling(sift_hip_ctx *c, int nslots)
     c->prof.resize((size_t)nslots);
     for (auto &ps : c->prof)
         for (int i = 0; i < SIFT_HIP_NSTAGES; i++)
-            for (int k = 0; k < 2; k++) HIP_TRY(hipEventCreate(&ps.ev[i][k]));
+            for (int k = 0; k < 2; k++) HIP_TRY(make_event(&ps.ev[i][k], hipEventDefault));
     return SIFT_HIP_OK;
 }
 
@@ -973,7 +1001,7 @@ int sift_hip_match(sift_hip_ctx *c, const uint32_t *query, int nquery, const uin
     if (c->match_cap < need) {
         if (c->d_match) (void)hipFree(c->d_match);
         c->d_match = nullptr; c->match_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_match, need));
+        HIP_TRY(dev_alloc(&c->d_match, need));
         c->match_cap = need;
     }
     uint8_t *d_q = c->d_match, *d_t = d_q + ((qb + 255) & ~(size_t)255), *d_m = d_t + ((tb + 255) & ~(size_t)255);
@@ -1018,7 +1046,7 @@ int sift_hip_gray_from_bgr(sift_hip_ctx *c, const uint8_t *bgr, long pitch, int 
     if (c->bgr_cap < bytes + gbytes) {
         if (c->d_bgr) (void)hipFree(c->d_bgr);
         c->d_bgr = nullptr; c->bgr_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_bgr, bytes + gbytes));
+        HIP_TRY(dev_alloc(&c->d_bgr, bytes + gbytes));
         c->bgr_cap = bytes + gbytes;
     }
     HIP_TRY(hipMemcpyAsync(c->d_bgr, bgr, bytes, hipMemcpyHostToDevice, s));
@@ -1124,10 +1152,10 @@ int ensure_top_buffers(sift_hip_ctx *c, int nfinal)
     if (c->top_cap >= n) return SIFT_HIP_OK;
     for (void *p : {(void *)c->d_tfinal, (void *)c->d_tindex, (void *)c->d_tdesc, (void *)c->d_tnvalid}) if (p) (void)hipFree(p);
     c->d_tfinal = nullptr; c->d_tindex = nullptr; c->d_tdesc = nullptr; c->d_tnvalid = nullptr; c->top_cap = 0;
-    HIP_TRY(hipMalloc(&c->d_tfinal, n * sizeof(sift::kp_t)));
-    HIP_TRY(hipMalloc(&c->d_tindex, n * 4));
-    HIP_TRY(hipMalloc(&c->d_tdesc, n * 72 * 4));
-    HIP_TRY(hipMalloc(&c->d_tnvalid, (size_t)c->max_batch * 4));
+    HIP_TRY(dev_alloc(&c->d_tfinal, n * sizeof(sift::kp_t)));
+    HIP_TRY(dev_alloc(&c->d_tindex, n * 4));
+    HIP_TRY(dev_alloc(&c->d_tdesc, n * 72 * 4));
+    HIP_TRY(dev_alloc(&c->d_tnvalid, (size_t)c->max_batch * 4));
     c->top_cap = n;
     return SIFT_HIP_OK;
 }
@@ -1151,41 +1179,38 @@ int batch_impl(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *imgs, 
             return fail(SIFT_HIP_EINVAL, "contexts differ in frame size or max_keypoints");
     }
     for (int f = 0; f < nframes; f++) if (!imgs[f]) return fail(SIFT_HIP_EINVAL, "null frame");
-    if (nfinal)
-        for (int i = 0; i < nctx; i++) {
-            DevGuard g(ctxs[i]->device);
-            if (int r = ensure_top_buffers(ctxs[i], nfinal)) return r;
-        }
-    // one host thread per context (= per GPU); context i takes frames i, i+nctx, ...  No exchange
-    // between contexts.  Inside a context the frames go through in chunks of half its max_batch,
-    // double buffered: the H2D copy of chunk k+1 and the D2H copy of chunk k-1 run on their own
-    // streams beside the kernels of chunk k (the overlapped ingest of main.cpp:41-58 / :82-184).
+    for (int i = 0; i < nctx; i++) {
+        DevGuard g(ctxs[i]->device);
+        if (int r = ensure_batch_streams(ctxs[i])) return r;
+        if (nfinal) if (int r = ensure_top_buffers(ctxs[i], nfinal)) return r;
+    }
+    // One host thread per context (= per GPU).  Context i takes the contiguous range of frames
+    // sift_hip_batch_range gives it (ceil(nframes / nctx) each), so whatever the number of
+    // contexts a chunk's frames are neighbours in the caller's arrays: its results go back as one copy per
+    // array, and frames that lie back to back in host memory go up as one copy.  No exchange between
+    // contexts.  Inside a context the frames go through in chunks of half its max_batch, double buffered:
+    // the H2D copy of chunk k+1 and the D2H copy of chunk k-1 run on the context's two copy streams beside the
+    // kernels of chunk k (the overlapped ingest of main.cpp:41-58 / :82-184).  Streams and events belong to
+    // the context: a call creates nothing.
     std::vector<int> rc(nctx, SIFT_HIP_OK);
     std::vector<std::string> msg(nctx);
     auto worker = [&](int ci) {
         sift_hip_ctx *c = ctxs[ci];
         DevGuard g(c->device);
         const size_t np = c->npix, K = (size_t)c->max_kp;
-        std::vector<int> mine;
-        for (int f = ci; f < nframes; f += nctx) mine.push_back(f);
-        if (mine.empty()) return;
+        int first = 0, last = 0;
+        sift_hip_batch_range(nframes, nctx, ci, &first, &last);
+        if (first >= last) return;
         auto step = [&](hipError_t e, const char *what) {
             if (e != hipSuccess && rc[ci] == SIFT_HIP_OK) { rc[ci] = SIFT_HIP_EHIP; msg[ci] = std::string(what) + ": " + hipGetErrorString(e); }
         };
         const int half = c->max_batch >= 2 ? c->max_batch / 2 : c->max_batch;   // frames per chunk
         const int nbuf = c->max_batch >= 2 ? 2 : 1;
-        hipStream_t s_in = nullptr, s_out = nullptr, s = c->stream;
-        hipEvent_t in_done[2] = {}, k_done[2] = {}, out_done[2] = {};
-        step(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking), "stream");
-        step(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking), "stream");
-        for (int i = 0; i < 2; i++) {
-            step(hipEventCreateWithFlags(&in_done[i], hipEventDisableTiming), "event");
-            step(hipEventCreateWithFlags(&k_done[i], hipEventDisableTiming), "event");
-            step(hipEventCreateWithFlags(&out_done[i], hipEventDisableTiming), "event");
-        }
+        hipStream_t s_in = c->s_in, s_out = c->s_out, s = c->stream;
+        hipEvent_t *in_done = c->in_done, *k_done = c->k_done, *out_done = c->out_done;
         size_t chunk = 0;
-        for (size_t b0 = 0; b0 < mine.size() && rc[ci] == SIFT_HIP_OK; b0 += (size_t)half, chunk++) {
-            const int nb = (int)std::min((size_t)half, mine.size() - b0);
+        for (int b0 = first; b0 < last && rc[ci] == SIFT_HIP_OK; b0 += half, chunk++) {
+            const int nb = std::min(half, last - b0);
             const int h = (int)(chunk % (size_t)nbuf);
             uint8_t *d_img = c->d_img + (size_t)h * half * np;
             sift::kp_t *d_kps = c->d_kps + (size_t)h * half * K;
@@ -1197,11 +1222,11 @@ int batch_impl(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *imgs, 
             for (int k = 0; k < nb;) {
                 int run = 1;
                 if (c->Wl == c->W)
-                    while (k + run < nb && imgs[mine[b0 + k + run]] == imgs[mine[b0 + k]] + (size_t)run * host_frame) run++;
+                    while (k + run < nb && imgs[b0 + k + run] == imgs[b0 + k] + (size_t)run * host_frame) run++;
                 if (run > 1)
-                    step(hipMemcpyAsync(d_img + (size_t)k * np, imgs[mine[b0 + k]], (size_t)run * np, hipMemcpyHostToDevice, s_in), "H2D frames");
+                    step(hipMemcpyAsync(d_img + (size_t)k * np, imgs[b0 + k], (size_t)run * np, hipMemcpyHostToDevice, s_in), "H2D frames");
                 else
-                    step(upload_frame(c, d_img + (size_t)k * np, imgs[mine[b0 + k]], s_in), "H2D frame");
+                    step(upload_frame(c, d_img + (size_t)k * np, imgs[b0 + k], s_in), "H2D frame");
                 k += run;
             }
             step(hipEventRecord(in_done[h], s_in), "record");
@@ -1220,12 +1245,10 @@ int batch_impl(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *imgs, 
                 }
             }
             step(hipEventRecord(k_done[h], s), "record");
-            // D2H
+            // D2H: the chunk's frames are consecutive in the caller's arrays, one copy per array
             step(hipStreamWaitEvent(s_out, k_done[h], 0), "wait");
-            // with one context the chunk's frames are consecutive in the caller's arrays: one copy per array
-            const bool consecutive = nctx == 1;
-            if (consecutive && rc[ci] == SIFT_HIP_OK) {
-                const size_t f = (size_t)mine[b0], n = (size_t)nb;
+            if (rc[ci] == SIFT_HIP_OK) {
+                const size_t f = (size_t)b0, n = (size_t)nb;
                 if (!nfinal) {
                     step(hipMemcpyAsync(kps + f * K, d_kps, n * K * 8, hipMemcpyDeviceToHost, s_out), "D2H keypoints");
                     step(hipMemcpyAsync(desc + f * K * 72, d_desc, n * K * 72 * 4, hipMemcpyDeviceToHost, s_out), "D2H descriptors");
@@ -1237,31 +1260,12 @@ int batch_impl(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *imgs, 
                     if (nvalid) step(hipMemcpyAsync(nvalid + f, c->d_tnvalid + (size_t)h * half, n * 4, hipMemcpyDeviceToHost, s_out), "D2H counts");
                 }
             }
-            for (int k = 0; k < nb && rc[ci] == SIFT_HIP_OK && !consecutive; k++) {
-                const size_t f = (size_t)mine[b0 + k];
-                if (!nfinal) {
-                    step(hipMemcpyAsync(kps + f * K, d_kps + (size_t)k * K, K * 8, hipMemcpyDeviceToHost, s_out), "D2H keypoints");
-                    step(hipMemcpyAsync(desc + f * K * 72, d_desc + (size_t)k * K * 72, K * 72 * 4, hipMemcpyDeviceToHost, s_out), "D2H descriptors");
-                } else {
-                    const size_t NF = (size_t)nfinal, o = ((size_t)h * half + (size_t)k) * NF;
-                    step(hipMemcpyAsync(final_kps + f * NF, c->d_tfinal + o, NF * 8, hipMemcpyDeviceToHost, s_out), "D2H final keypoints");
-                    if (final_index) step(hipMemcpyAsync(final_index + f * NF, c->d_tindex + o, NF * 4, hipMemcpyDeviceToHost, s_out), "D2H slots");
-                    if (final_desc) step(hipMemcpyAsync(final_desc + f * NF * 72, c->d_tdesc + o * 72, NF * 72 * 4, hipMemcpyDeviceToHost, s_out), "D2H descriptor rows");
-                    if (nvalid) step(hipMemcpyAsync(nvalid + f, c->d_tnvalid + (size_t)h * half + (size_t)k, 4, hipMemcpyDeviceToHost, s_out), "D2H counts");
-                }
-            }
             step(hipEventRecord(out_done[h], s_out), "record");
         }
-        if (s_in) step(hipStreamSynchronize(s_in), "sync");
+        // all three streams drain before the call returns, whatever happened above
+        step(hipStreamSynchronize(s_in), "sync");
         step(hipStreamSynchronize(s), "sync");
-        if (s_out) step(hipStreamSynchronize(s_out), "sync");
-        for (int i = 0; i < 2; i++) {
-            if (in_done[i]) (void)hipEventDestroy(in_done[i]);
-            if (k_done[i]) (void)hipEventDestroy(k_done[i]);
-            if (out_done[i]) (void)hipEventDestroy(out_done[i]);
-        }
-        if (s_in) (void)hipStreamDestroy(s_in);
-        if (s_out) (void)hipStreamDestroy(s_out);
+        step(hipStreamSynchronize(s_out), "sync");
     };
     if (nctx == 1) {
         worker(0);
@@ -1278,6 +1282,20 @@ int batch_impl(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *imgs, 
 }  // namespace
 
 extern "C" {
+
+int sift_hip_batch_range(int nframes, int nctx, int i, int *first, int *last)
+{
+    if (nframes < 0 || nctx < 1 || i < 0 || i >= nctx || !first || !last) return fail(SIFT_HIP_EINVAL, "bad partition");
+    const long per = ((long)nframes + nctx - 1) / nctx;
+    *first = (int)std::min((long)nframes, (long)i * per);
+    *last = (int)std::min((long)nframes, (long)*first + per);
+    return SIFT_HIP_OK;
+}
+
+long sift_hip_debug_created(int what)
+{
+    return (what >= 0 && what < 3) ? g_created[what].load() : -1;
+}
 
 int sift_hip_batch(sift_hip_ctx *const *ctxs, int nctx, const uint8_t *const *imgs, int nframes, sift_keypoint *kps,
                    uint32_t *desc, int contrastTh)
@@ -1448,15 +1466,10 @@ int sift_hip_next_octave(sift_hip_ctx *c, int frame, int plane, uint8_t *dst)
     const size_t n = (size_t)(c->Wl / 2) * (size_t)(c->H / 2);
     if (!n) return fail(SIFT_HIP_EINVAL, "frame too small for another octave");
     DevGuard g(c->device);
-    uint8_t *d = nullptr;
-    HIP_TRY(hipMalloc(&d, n));
-    int r = sift_hip_next_octave_dev(c, frame, 1, plane, d, c->stream);
-    hipError_t e = hipSuccess;
-    if (!r) e = hipMemcpyAsync(dst, d, n, hipMemcpyDeviceToHost, c->stream);
-    if (!r && e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
-    if (r) return r;
-    if (e != hipSuccess) return fail(SIFT_HIP_EHIP, "next octave", e);
+    if (!c->d_oct) HIP_TRY(dev_alloc(&c->d_oct, n));      // the size is the context's: allocated once, kept
+    if (int r = sift_hip_next_octave_dev(c, frame, 1, plane, c->d_oct, c->stream)) return r;
+    HIP_TRY(hipMemcpyAsync(dst, c->d_oct, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return SIFT_HIP_OK;
 }
 
@@ -1485,9 +1498,9 @@ int sift_hip_debug_planes(sift_hip_ctx *c, int frame, uint8_t *g1, uint8_t *g2, 
     if (cand || eratio || surv) {
         uint16_t *d_c = nullptr, *d_s = nullptr;
         int32_t *d_e = nullptr;
-        HIP_TRY(hipMalloc(&d_c, nl * 2));
-        HIP_TRY(hipMalloc(&d_s, nl * 2));
-        HIP_TRY(hipMalloc(&d_e, nl * 4));
+        HIP_TRY(dev_alloc(&d_c, nl * 2));
+        HIP_TRY(dev_alloc(&d_s, nl * 2));
+        HIP_TRY(dev_alloc(&d_e, nl * 4));
         const size_t HS = (size_t)c->H * c->S;
         dim3 grid((c->Wl + 255) / 256, c->H);
         hipLaunchKernelGGL(sift::k_expand_maps, grid, dim3(256), 0, c->stream, c->d_cand + frame * HS,

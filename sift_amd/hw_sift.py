@@ -234,7 +234,8 @@ class SiftContext:
 
 
 def batch(contexts, imgs, contrastTh=15):
-    """sift_hip_batch: frame f -> contexts[f % len(contexts)]; returns (kps[n,K], desc[n,K,72])."""
+    """sift_hip_batch: context i takes the contiguous frame range batch_range(n, len(contexts), i);
+    returns (kps[n,K], desc[n,K,72])."""
     lib = load_library()
     c0 = contexts[0]
     imgs = [c0._img(im) for im in imgs]
@@ -245,6 +246,19 @@ def batch(contexts, imgs, contrastTh=15):
     ps = (C.c_void_p * max(n, 1))(*[im.ctypes.data for im in imgs])
     check(lib.sift_hip_batch(hs, len(contexts), ps, n, _vp(kps), _vp(desc), int(contrastTh)))
     return kps, desc
+
+
+def batch_range(nframes, nctx, i):
+    """the partition rule of sift_hip_batch (needs no device): (first, last) of context i's frames"""
+    a, b = C.c_int(0), C.c_int(0)
+    check(load_library().sift_hip_batch_range(int(nframes), int(nctx), int(i), C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def created_counts():
+    """(streams, events, device buffers) the library has created in this process so far"""
+    lib = load_library()
+    return tuple(int(lib.sift_hip_debug_created(k)) for k in range(3))
 
 
 def batch_top(contexts, imgs, nfinal=MAX_FINAL_KEYPOINTS, contrastTh=15):

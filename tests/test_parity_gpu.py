@@ -255,17 +255,52 @@ def test_batched_device_entry_points(sift, orc):
 
 
 def test_host_batch_call(sift, orc):
-    """sift_hip_batch: the image loop of main.cpp:37-210, frames dealt over contexts."""
-    from sift_amd.hw_sift import batch
+    """sift_hip_batch: the image loop of main.cpp:37-210, contiguous frame ranges over contexts (SURVEY.md 8(e));
+    three contexts take 11 frames as 4 + 4 + 3, chunked by their own max_batch."""
+    from sift_amd.hw_sift import batch, batch_top
     W, H = 320, 240
-    imgs = [orc.synth_frame(s, W, H) for s in range(40, 47)]
-    with sift.SiftContext(W, H, max_batch=2) as a, sift.SiftContext(W, H, max_batch=3) as b:
-        for ctxs in ([a], [a, b]):
-            kps, desc = batch(ctxs, imgs)
-            for f, im in enumerate(imgs):
-                rk, rd, _ = orc.detect_and_compute(im)
-                n = nvalid(rk)
-                assert (kps[f] == rk).all() and (desc[f, :n] == rd[:n]).all() and not desc[f, n:].any()
+    imgs = [orc.synth_frame(s, W, H) for s in range(40, 51)]
+    ref = [orc.detect_and_compute(im) for im in imgs]
+    with sift.SiftContext(W, H, max_batch=2) as a, sift.SiftContext(W, H, max_batch=3) as b, \
+            sift.SiftContext(W, H, max_batch=8) as c:
+        for ctxs, n in (([a], 7), ([a, b], 7), ([a, b, c], 11), ([c, b, a], 11), ([a, b, c], 2), ([b], 0)):
+            kps, desc = batch(ctxs, imgs[:n])
+            assert kps.shape[0] == n
+            for f in range(n):
+                rk, rd, _ = ref[f]
+                m = nvalid(rk)
+                assert (kps[f] == rk).all() and (desc[f, :m] == rd[:m]).all() and not desc[f, m:].any(), (len(ctxs), n, f)
+        # frames that are neighbours in host memory (one array): the run-length upload path
+        block = np.stack(imgs)
+        kps, desc = batch([a, b, c], list(block))
+        for f in range(len(imgs)):
+            assert (kps[f] == ref[f][0]).all()
+        fin, idx, fdesc, nv = batch_top([a, b, c], imgs, 100)
+        for f in range(len(imgs)):
+            rf, ri, rn = orc.select_top(ref[f][0], 100)
+            assert (fin[f] == rf).all() and (idx[f] == ri).all() and nv[f] == rn
+            assert (fdesc[f] == ref[f][1][ri]).all()
+
+
+def test_batch_call_creates_nothing_the_second_time(sift, orc):
+    """The context replaces the reference's per-call allocation (HW_SIFT.cpp:23-24): the copy streams, events and
+    staging buffers of sift_hip_batch[_top] and sift_hip_next_octave are made once per context."""
+    from sift_amd.hw_sift import batch, batch_top, created_counts
+    W, H = 320, 240
+    imgs = [orc.synth_frame(s, W, H) for s in range(60, 69)]
+    with sift.SiftContext(W, H, max_batch=4) as a, sift.SiftContext(W, H, max_batch=2) as b:
+        before = created_counts()
+        k1, d1 = batch([a, b], imgs)
+        t1 = batch_top([a, b], imgs, 50)
+        o1 = a.next_octave(0, 2)
+        first = created_counts()
+        assert first[0] - before[0] == 4 and first[1] - before[1] == 12 and first[2] > before[2]
+        k2, d2 = batch([a, b], imgs)
+        t2 = batch_top([a, b], imgs, 50)
+        o2 = a.next_octave(0, 2)
+        assert created_counts() == first, "a repeated call created a stream, an event or a device buffer"
+        assert (k1 == k2).all() and (d1 == d2).all() and (o1 == o2).all()
+        assert all((x == y).all() for x, y in zip(t1, t2))
 
 
 def test_repeated_calls_are_idempotent(sift, orc):

@@ -21,6 +21,18 @@ def test_frame_ranges_cover_every_frame_once():
         frame_range(10, 2, 2)
 
 
+def test_library_partitions_like_frame_range():
+    """sift_hip_batch's rule (sift_hip_batch_range, no device needed) is shard.frame_range: SURVEY.md 8(e)"""
+    from sift_amd.hw_sift import batch_range
+    from sift_amd.capi import SiftHipError
+    for n in (0, 1, 7, 8, 11, 40, 41, 1000):
+        for g in (1, 2, 3, 4, 8):
+            for r in range(g):
+                assert batch_range(n, g, r) == frame_range(n, r, g)
+    with pytest.raises(SiftHipError):
+        batch_range(10, 2, 2)
+
+
 def test_frame_seeds_disjoint():
     s = [frame_seeds(1, 16, r) for r in range(8)]
     flat = sum(s, [])
