@@ -49,7 +49,10 @@ def parse_args(argv=None):
     ap.add_argument("--contrast-th", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the comparison with the oracle's fixture (kernel experiments)")
-    ap.add_argument("--no-overlap", action="store_true", help="skip the two-stream pass")
+    ap.add_argument("--overlap", action="store_true",
+                    help="also time the steps alternating between two contexts (two streams); level with or slower than one "
+                         "stream since the blur runs on the matrix cores, so not part of the default run")
+    ap.add_argument("--no-overlap", action="store_true", help="(default; kept for older scripts)")
     ap.add_argument("--no-profile-events", action="store_true", help="leave the per-kernel HIP events out")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the 640x480 and 3840x2160 passes")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the pinned-host-buffer passes")
@@ -163,13 +166,14 @@ def check_outputs(seeds, d_kps, d_desc, totals, expected, what):
     return len(seeds)
 
 
-def run_config(sift_amd, torch, dev, W, H, seeds, steps, warmup, th, spin_s=0.5, profile=True):
-    """frames of `seeds` resident on GPU `dev`, a context, spin-up and warm-up steps done ->
+def run_config(sift_amd, torch, dev, W, H, seeds, steps, warmup, th, spin_s=0.5, profile=True, d_img=None):
+    """frames of `seeds` (or the frames in d_img) resident on GPU `dev`, a context, spin-up and warm-up steps done ->
     (context, the step function, (d_img, d_kps, d_desc, d_tot))"""
     from sift_amd.synth import synth_frames_torch
     B, K = len(seeds), sift_amd.MAX_KEYPOINTS
     device = "cuda:%d" % dev
-    d_img = torch.cat([synth_frames_torch(seeds[i:i + 32], W, H, device) for i in range(0, B, 32)])
+    if d_img is None:
+        d_img = torch.cat([synth_frames_torch(seeds[i:i + 32], W, H, device) for i in range(0, B, 32)])
     d_kps = torch.zeros((B, K, 2), dtype=torch.int32, device=device)
     d_desc = torch.zeros((B, K, 72), dtype=torch.int32, device=device)
     d_tot = torch.zeros(B, dtype=torch.int32, device=device)
@@ -221,6 +225,111 @@ def other_config(sift_amd, torch, dev, W, H, B, th, steps=10, warmup=2):
             "value": B * steps / el, "unit": "frames/s", "ms_per_step": 1e3 * el / steps,
             "keypoints_per_frame_mean": float(np.minimum(totals, sift_amd.MAX_KEYPOINTS).mean()),
             "kernel_ms_per_step": stage, "checked_frames": checked}
+
+
+def im0_config(sift_amd, torch, dev, th, B=256, steps=10, warmup=2, with_cpu=True):
+    """BASELINE.json configs[0]: the reference's test image (src/data/im0.jpg as the committed 8-bit gray
+    fixture, 218 keypoints: the sparse regime), a batch of B copies of it device-resident, and the oracle on it
+    on one host core.  Every frame's outputs are compared with tests/golden/im0_expected.npz."""
+    from PIL import Image
+    g = os.path.join(ROOT, "tests", "golden")
+    im0 = np.ascontiguousarray(np.asarray(Image.open(os.path.join(g, "im0_gray_1920x1080.png")), dtype=np.uint8))
+    z = np.load(os.path.join(g, "im0_expected.npz"))
+    H, W = im0.shape
+    K, n = sift_amd.MAX_KEYPOINTS, len(z["kps"])
+    d_img = torch.from_numpy(im0).to("cuda:%d" % dev).unsqueeze(0).repeat(B, 1, 1).contiguous()
+    ctx, step, (d_img, d_kps, d_desc, d_tot) = run_config(sift_amd, torch, dev, W, H, list(range(B)), steps, warmup, th,
+                                                            spin_s=0.1, d_img=d_img)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.sync()
+    el = time.perf_counter() - t0
+    stage, _ = stage_summary(sift_amd, ctx)
+    ctx.close()
+    checked = 0
+    if th == 15:
+        gk = d_kps[0].cpu().numpy().view(sift_amd.KP_DTYPE).reshape(K)
+        gd = d_desc[0].cpu().numpy().view(np.uint32)
+        same = bool((d_kps == d_kps[0]).all() and (d_desc == d_desc[0]).all() and (d_tot == n).all())
+        if not ((gk[:n] == z["kps"]).all() and not gk[n:].view(np.uint64).any() and (gd[:n] == z["desc"]).all()
+                and not gd[n:].any() and same):
+            raise SystemExit("wrong result (im0): the frames differ from tests/golden/im0_expected.npz")
+        checked = B
+    out = {"workload": "reference test image im0 (1920x1080 gray, configs[0]), full pipeline", "frames_per_step": B,
+           "steps": steps, "value": B * steps / el, "unit": "frames/s", "ms_per_step": 1e3 * el / steps,
+           "keypoints_per_frame_mean": float(n), "kernel_ms_per_step": stage, "checked_frames": checked}
+    if with_cpu:
+        from oracle import oracle as orc
+        orc.detect_and_compute(im0, th)
+        t0, reps = time.perf_counter(), 3
+        for _ in range(reps):
+            rk, rd, total = orc.detect_and_compute(im0, th)
+        dt = time.perf_counter() - t0
+        if th == 15 and not (total == n and (rk[:n] == z["kps"]).all() and (rd[:n] == z["desc"]).all()):
+            raise SystemExit("the oracle's im0 outputs differ from tests/golden/im0_expected.npz")
+        out["cpu_baseline"] = {"value": reps / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": "%d passes over im0, full pipeline, %.1f s" % (reps, dt)}
+    return out
+
+
+def octave_config(sift_amd, torch, dev, W, H, B, th, steps=6, warmup=2, with_cpu=True, oracle_frames=2):
+    """BASELINE.json configs[3], "4K frames, extra octave": the reference has one octave, so the
+    second one is this build's extension (include/sift_hip.h, "further octaves": pixel (2x, 2y) of G2 through the
+    unchanged pipeline at half size) -- PARITY UNPINNED.  A step = octave 0 of B frames, the decimation, octave 1
+    of the B half-size frames, all on one stream, device-resident.  Octave 0 is checked against the oracle's
+    fixture, both octaves of the first frames against the oracle's composition run here."""
+    from sift_amd.synth import synth_frames_torch
+    K, device = sift_amd.MAX_KEYPOINTS, "cuda:%d" % dev
+    seeds = list(range(1, B + 1))
+    W1, H1 = W // 2, H // 2
+    d_img = torch.cat([synth_frames_torch(seeds[i:i + 16], W, H, device) for i in range(0, B, 16)])
+    d_img1 = torch.zeros((B, H1, W1), dtype=torch.uint8, device=device)
+    outs = [(torch.zeros((B, K, 2), dtype=torch.int32, device=device), torch.zeros((B, K, 72), dtype=torch.int32, device=device),
+             torch.zeros(B, dtype=torch.int32, device=device)) for _ in range(2)]
+    c0 = sift_amd.SiftContext(W, H, device=dev, max_batch=B)
+    c1 = sift_amd.SiftContext(W1, H1, device=dev, max_batch=B)
+    stream = torch.cuda.Stream(device=device)
+    sp = stream.cuda_stream
+
+    def step():
+        c0.detect_and_compute_dev(d_img, B, outs[0][0], outs[0][1], outs[0][2], th, stream=sp)
+        c0.next_octave_dev(0, B, d_img1, plane=2, stream=sp)
+        c1.detect_and_compute_dev(d_img1, B, outs[1][0], outs[1][1], outs[1][2], th, stream=sp)
+
+    for _ in range(warmup):
+        step()
+    stream.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    stream.synchronize()
+    el = time.perf_counter() - t0
+    tot0, tot1 = outs[0][2].cpu().numpy(), outs[1][2].cpu().numpy()
+    checked = check_outputs(seeds, outs[0][0], outs[0][1], tot0, expected_for(W, H, th), "%dx%d, octave 0" % (W, H))
+    out = {"workload": "%dx%d synthetic frames + one further octave (%dx%d), full pipeline per octave (configs[3]); the second "
+                       "octave is an extension, parity unpinned" % (W, H, W1, H1),
+           "frames_per_step": B, "steps": steps, "value": B * steps / el, "unit": "frames/s", "ms_per_step": 1e3 * el / steps,
+           "keypoints_per_frame_mean": [float(np.minimum(tot0, K).mean()), float(np.minimum(tot1, K).mean())],
+           "checked_frames": checked}
+    if with_cpu:
+        from oracle import oracle as orc
+        t0 = time.perf_counter()
+        for i in range(oracle_frames):
+            want = orc.detect_and_compute_octaves(orc.synth_frame(seeds[i], W, H), 2, th)
+            for o, (rk, rd, total) in enumerate(want):
+                n = int((rk["contrast"] > 0).sum())
+                gk = outs[o][0][i].cpu().numpy().view(sift_amd.KP_DTYPE).reshape(K)
+                gd = outs[o][1][i].cpu().numpy().view(np.uint32)
+                if not ((gk == rk).all() and (gd[:n] == rd[:n]).all() and not gd[n:].any() and int((tot0, tot1)[o][i]) == total):
+                    raise SystemExit("wrong result (%dx%d + octave): octave %d of seed %d differs from the oracle's composition" % (W, H, o, seeds[i]))
+        dt = time.perf_counter() - t0
+        out["checked_frames_both_octaves"] = oracle_frames
+        out["cpu_baseline"] = {"value": oracle_frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": "%d synthetic %dx%d frames, both octaves, %.1f s" % (oracle_frames, W, H, dt)}
+    c0.close(); c1.close()
+    return out
 
 
 def end_to_end(sift_amd, dev, W, H, th, expected, frames_per_call=128, calls=8, max_batch=64, nfinal=1000):
@@ -295,7 +404,7 @@ def main():
 
     import torch
     import sift_amd
-    from sift_amd.shard import DistEnv, frame_range, frame_seeds, pick_device
+    from sift_amd.shard import DistEnv, check_ranks, device_identity, frame_range, frame_seeds, pick_device
 
     # SIFT_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N>1 path on a
     # one-GPU box; RCCL refuses two ranks on one device).  The driver's runs use RCCL ("nccl").
@@ -307,6 +416,13 @@ def main():
     if env.world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, env.world))
     torch.cuda.set_device(dev)
+    # before anything is timed: the process group (RCCL on a node) holds the N ranks asked for, each on a GPU of its own
+    identities = env.gather_ints(device_identity(torch.cuda.get_device_properties(dev), dev))
+    try:
+        check_ranks(a.gpus, env.dist_world_size(), identities, shared_ok=(backend == "gloo"))
+    except RuntimeError as e:
+        raise SystemExit("bench.py: %s" % e)
+    devices = env.gather_ints(dev)
     W, H, K, th = a.width, a.height, sift_amd.MAX_KEYPOINTS, a.contrast_th
 
     if a.scaling == "weak":
@@ -347,7 +463,7 @@ def main():
     # describe kernel of one batch runs beside the VALU-bound blur of the next.  Reported as
     # "overlapped"; `value` and the per-kernel times above are the plain one-stream loop.
     overlapped = None
-    if not a.no_overlap:
+    if a.overlap:
         ctx2 = sift_amd.SiftContext(W, H, device=dev, max_batch=B)
         d_kps2, d_desc2, d_tot2 = torch.zeros_like(d_kps), torch.zeros_like(d_desc), torch.zeros_like(d_tot)
         ctx.set_profiling(0)
@@ -395,7 +511,11 @@ def main():
     torch.cuda.empty_cache()
     others = e2e = None
     if a.gpus == 1 and (W, H) == (1920, 1080) and not a.no_other_configs:
-        others = [other_config(sift_amd, torch, dev, 640, 480, 256, th), other_config(sift_amd, torch, dev, 3840, 2160, 64, th)]
+        with_cpu = not a.no_cpu_baseline
+        others = [im0_config(sift_amd, torch, dev, th, with_cpu=with_cpu),
+                  other_config(sift_amd, torch, dev, 640, 480, 256, th), other_config(sift_amd, torch, dev, 3840, 2160, 64, th)]
+        torch.cuda.empty_cache()
+        others.append(octave_config(sift_amd, torch, dev, 3840, 2160, 64, th, with_cpu=with_cpu))
         torch.cuda.empty_cache()
     if a.gpus == 1 and not a.no_end_to_end:
         e2e = end_to_end(sift_amd, dev, W, H, th, None if a.no_check else expected)
@@ -412,6 +532,8 @@ def main():
                        "frames_per_step_per_gpu": B, "frames_per_step": nframes // a.steps, "contrast_th": th,
                        "max_keypoints": K, "keypoints_per_frame_mean": kp_mean,
                        "parallelism": "frames x%d" % a.gpus, "resident": "inputs and outputs in HBM"},
+            "ranks_seen": env.dist_world_size(), "devices": devices, "distinct_gpus": len(set(identities)),
+            "backend": env.backend if env.world > 1 else None,
             "checked_frames": checked,
             "checked_what": "total, keypoint array and descriptor matrix of every frame of the last step against the oracle's fixture "
                             "(tests/golden/bench_expected.json)" + ("; %d frames also word by word against the oracle run in this process" % oracle_checked if oracle_checked else ""),

@@ -32,6 +32,34 @@ def pick_device(local_rank, visible, share=False):
     raise RuntimeError("LOCAL_RANK %d but only %d GPUs visible" % (local_rank, visible))
 
 
+def device_identity(props, index):
+    """an int that names the physical GPU behind device `index` of this process: ranks that each see one
+    device through a visibility mask all call it device 0, so the index alone cannot tell whether two
+    ranks share a GPU.  From the device properties' uuid, else its PCI address, else the index."""
+    uuid = getattr(props, "uuid", None)
+    if uuid is not None:
+        raw = getattr(uuid, "bytes", None)
+        if raw is not None:                       # bytes, or a list of (possibly signed) byte values
+            digits = bytes(int(v) & 0xFF for v in raw).hex()
+        else:
+            digits = "".join(ch for ch in str(uuid) if ch in "0123456789abcdefABCDEF")
+        if digits and int(digits, 16):
+            return int(digits, 16) & ((1 << 62) - 1)
+    pci = [getattr(props, n, None) for n in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+    if pci[1] is not None:
+        return (1 << 40) | int(pci[0] or 0) << 16 | int(pci[1]) << 8 | int(pci[2] or 0)
+    return int(index)
+
+
+def check_ranks(world_expected, world_seen, identities, shared_ok):
+    """what bench.py asserts before it times N > 1 ranks: the process group holds the N ranks asked for, and
+    no two of them sit on one GPU (unless the gloo rehearsal on a one-GPU box asked for that)"""
+    if world_seen != world_expected or len(identities) != world_expected:
+        raise RuntimeError("asked for %d ranks, the process group has %d (%d answered)" % (world_expected, world_seen, len(identities)))
+    if not shared_ok and len(set(identities)) != len(identities):
+        raise RuntimeError("two ranks share a GPU: device identities %r" % (identities,))
+
+
 class DistEnv:
     """One process per GPU, launched by torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*)."""
 
@@ -81,6 +109,20 @@ class DistEnv:
         t = torch.tensor([int(value)], dtype=torch.int64, device=self._device)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
         return int(t.item())
+
+    def gather_ints(self, value):
+        """every rank's `value` (an int below 2^63), in rank order"""
+        if self._dist is None:
+            return [int(value)]
+        import torch
+        mine = torch.tensor([int(value)], dtype=torch.int64, device=self._device)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        self._dist.all_gather(out, mine)
+        return [int(t.item()) for t in out]
+
+    def dist_world_size(self):
+        """the world size the process group itself reports (1 without one)"""
+        return 1 if self._dist is None else int(self._dist.get_world_size())
 
     def close(self):
         if self._dist is not None and self._dist.is_initialized():

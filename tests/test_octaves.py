@@ -61,10 +61,11 @@ def test_octave_chain_against_the_oracle(sift, orc, W, H, noct):
 
 
 @pytest.mark.gpu
-def test_batched_octave_chain_on_the_device(sift, orc):
-    """three frames, two octaves, device buffers only: ctx0 -> next_octave_dev -> ctx1"""
+@pytest.mark.parametrize("W,H,B", [(640, 480, 3), (3840, 2160, 2)])
+def test_batched_octave_chain_on_the_device(sift, orc, W, H, B):
+    """a few frames, two octaves, device buffers only: ctx0 -> next_octave_dev -> ctx1; the second case is
+    BASELINE.json configs[3] ("4K frames, extra octave"), the shape bench.py times"""
     import torch
-    W, H, B = 640, 480, 3
     frames = np.stack([orc.synth_frame(20 + i, W, H) for i in range(B)])
     dev = torch.device("cuda:0")
     d_img = torch.from_numpy(frames).to(dev)

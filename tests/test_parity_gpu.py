@@ -643,6 +643,8 @@ def test_bench_two_ranks_sharing_the_gpu(sift):
         assert d["config"]["frames_per_step_per_gpu"] == per_gpu and d["config"]["frames_per_step"] == total
         assert abs(d["value"] * d["ms_per_step"] * 1e-3 - total) < 1e-6 * total + 1e-9
         assert "cpu_baseline" not in d and "other_configs" not in d
+        # the line proves how many ranks the process group held and where they ran (here: both on the one GPU)
+        assert d["ranks_seen"] == 2 and d["devices"] == [0, 0] and d["distinct_gpus"] == 1 and d["backend"] == "gloo"
 
 
 def test_cam1_geometry(sift, orc):

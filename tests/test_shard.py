@@ -33,6 +33,26 @@ def test_library_partitions_like_frame_range():
         batch_range(10, 2, 2)
 
 
+def test_rank_and_device_checks():
+    """what bench.py asserts before timing N > 1 ranks (the line must prove RCCL saw N ranks)"""
+    from types import SimpleNamespace as NS
+    from sift_amd.shard import check_ranks, device_identity
+    check_ranks(1, 1, [5], False)
+    check_ranks(4, 4, [1, 2, 3, 4], False)
+    check_ranks(2, 2, [7, 7], True)                                  # the gloo rehearsal on a one-GPU box
+    for bad in ((4, 2, [1, 2], False), (2, 2, [7, 7], False), (2, 2, [7], False)):
+        with pytest.raises(RuntimeError):
+            check_ranks(*bad)
+    a = device_identity(NS(uuid=NS(bytes=bytes(range(1, 17)))), 0)
+    b = device_identity(NS(uuid=NS(bytes=bytes(range(2, 18)))), 0)
+    assert a != b and 0 < a < 2 ** 63 and 0 < b < 2 ** 63              # two masked ranks both call their GPU "device 0"
+    assert device_identity(NS(uuid="GPU-0123abcd"), 3) == 0x0123abcd
+    assert device_identity(NS(uuid=NS(bytes=[0, -1, 3])), 0) == 0x00ff03     # torch hands the bytes over as a list of ints
+    assert device_identity(NS(uuid=NS(bytes=bytes(16)), pci_domain_id=0, pci_bus_id=0x65, pci_device_id=0), 0) != \
+        device_identity(NS(uuid=NS(bytes=bytes(16)), pci_domain_id=0, pci_bus_id=0x75, pci_device_id=0), 0)
+    assert device_identity(NS(), 5) == 5
+
+
 def test_frame_seeds_disjoint():
     s = [frame_seeds(1, 16, r) for r in range(8)]
     flat = sum(s, [])
@@ -47,6 +67,7 @@ def _worker(rank, world, port, q):
     env.barrier()
     t = env.max_over_ranks(1.0 + rank)          # the slowest rank sets the job time
     total = env.sum_over_ranks(hi - lo)
+    assert env.gather_ints(100 + rank) == [100, 101] and env.dist_world_size() == 2
     q.put((rank, t, total))
     env.close()
 

@@ -10,7 +10,7 @@ while [ $# -gt 0 ] && [ "$1" != "--" ]; do LIBS+=("$1"); shift; done
 for r in 1 2; do for src in "${LIBS[@]}"; do
   v=$(basename "$src" .so)
   cp "$src" sift_amd/lib/libsift_hip.so || { echo "ab.sh: cannot copy $src"; exit 1; }
-  timeout -k 10 200 python bench.py --steps 15 --warmup 3 --no-cpu-baseline "$@" > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || { tail -3 gpurun_out/ab_$v.err; exit 1; }
+  timeout -k 10 200 python bench.py --steps 15 --warmup 3 --no-cpu-baseline --no-other-configs --no-end-to-end "$@" > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || { tail -3 gpurun_out/ab_$v.err; exit 1; }
   python - <<PY
 import json
 d=json.load(open("gpurun_out/ab_$v.json"))
