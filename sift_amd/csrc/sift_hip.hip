@@ -408,22 +408,23 @@ int pick_blur_rows(const sift_hip_ctx *c, int nframes)
     return best_rows;
 }
 
-// Strip length of k_blur_mfma: a wave takes 16 (strip, 16-pixel block) units and runs rows + 18
-// iterations; the chip holds 1024 waves (one per SIMD).  Few strips keep the 18 warm-up rows small,
-// many fill the chip when the batch is small: the cheapest of all strip counts by that model.
+// Strip length of k_blur_mfma: a wave takes 16 (strip, 8-pixel block) units and runs rows / 2 + 10 steps of
+// 18 MFMAs; the chip holds 2048 such waves (two per SIMD, one of each role).  Few strips keep the 10 warm-up
+// steps small, many fill the chip when the batch is small: the cheapest of all strip counts by that model.
 int pick_blur_mfma_rows(const sift_hip_ctx *c, int nframes)
 {
     if (c->blur_rows > 0) return std::min(c->blur_rows, c->H);
-    const int NB = (c->W + 15) / 16;
+    const int NB = sift::blur_mfma_blocks(c->W);
     double best = 1e300;
     int best_rows = c->H;
     for (int k = 1; k <= c->H; k++) {
-        const int rows = (c->H + k - 1) / k;
+        int rows = (c->H + k - 1) / k;
+        if (k > 1) rows = (rows + 1) & ~1;           // pairs of rows: an odd strip would compute one row twice
         if (rows < 8) break;
         const int strips = (c->H + rows - 1) / rows;
         const double waves = (double)((NB * strips + 15) / 16) * nframes;
         const double rounds = waves > 4096.0 ? waves / 1024.0 : std::ceil(waves / 1024.0);
-        const double cost = (rows + 18) * rounds;
+        const double cost = ((rows + 1) / 2 + 10) * rounds;
         if (cost < best * 0.999) { best = cost; best_rows = rows; }
     }
     return best_rows;
@@ -452,11 +453,12 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
 {
     const int W = c->W, H = c->H, S = c->S;
     c->last_frames = nframes;
-    // k_blur_mfma addresses a frame's pyr plane (4 bytes per pixel) through one 32-bit buffer descriptor
-    if (c->blur_mfma && c->npix * 4 < (1ull << 32)) {
+    // k_blur_mfma addresses a frame's pyr plane (4 bytes per pixel) through one 32-bit buffer descriptor, whose
+    // size has to stay at or below the offset the kernel uses for "dropped" (0xfffffff0)
+    if (c->blur_mfma && c->npix * 4 <= 0xfffffff0ull) {
         StageTimer t(c, ST_BLUR, s);
         const int rows = pick_blur_mfma_rows(c, nframes);
-        const int nstrips = (H + rows - 1) / rows, NB = (W + 15) / 16;
+        const int nstrips = (H + rows - 1) / rows, NB = sift::blur_mfma_blocks(W);
         const int waves = (NB * nstrips + 15) / 16;
         // workgroups of two unit groups (two waves of each role; two workgroups fill a CU's register file):
         // measured against one and four groups per workgroup, 1.42 - 1.49 ms against 1.52 and 1.54 - 1.61 per 256 frames

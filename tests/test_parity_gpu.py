@@ -431,7 +431,7 @@ def test_bench_line_contract(sift):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--width", "640", "--height", "480", "--batch", "8",
-                        "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=110, cwd=root)
+                        "--steps", "3", "--warmup", "1", "--overlap"], capture_output=True, text=True, timeout=110, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
@@ -451,7 +451,8 @@ def test_bench_line_contract(sift):
     assert d["end_to_end"]["sift_hip_batch_top"]["ms_per_call"]["p50"] > 0 and d["end_to_end"]["checked_frames"] == 16
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0 and cb["sample"]
-    assert d["overlapped"]["outputs_equal_one_stream"] is True
+    assert d["overlapped"]["outputs_equal_one_stream"] is True          # only with --overlap: not part of the default run
+    assert d["ranks_seen"] == 1 and d["devices"] == [0] and d["backend"] is None
 
 
 @pytest.mark.parametrize("dx,dy", [(5, 3), (2, 1), (3, 6)])
