@@ -186,6 +186,9 @@ struct BlurState {
     v4i flo[JL], fhi[JH];
 };
 
+// an empty use of a register: what is in flight into it has to land first
+template <class T> __device__ __forceinline__ void use_now(T &x) { asm volatile("" : "+v"(x)); }
+
 template <int WHICH>
 __device__ __forceinline__ void load_frags(BlurState<WHICH> &st, int lane)
 {
@@ -202,6 +205,10 @@ __device__ __forceinline__ void load_frags(BlurState<WHICH> &st, int lane)
         const uint4 q = t[(BH + s) * 64 + lane];
         st.fhi[s] = v4i{(int)q.x, (int)q.y, (int)q.z, (int)q.w};
     });
+    // a use of every fragment: the compiler waits for these loads here, before the loop, instead of counting them
+    // into the waits inside it (which run in every iteration)
+    static_for<0, JL>([&](auto ss) { use_now(st.flo[decltype(ss)::value]); });
+    static_for<0, JH>([&](auto ss) { use_now(st.fhi[decltype(ss)::value]); });
     const v4i zero = v4i{0, 0, 0, 0};
     static_for<0, JL>([&](auto ss) { st.acc[decltype(ss)::value] = zero; });
     static_for<0, JH>([&](auto ss) { st.hi[decltype(ss)::value] = zero; });
@@ -283,13 +290,12 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
     const uint32_t gmask = inside >= 4 ? ~0u : inside <= 0 ? 0u : (1u << (8 * inside)) - 1u;
 
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const uint32_t colofs = (uint32_t)(col0 + 4 * sh);
-    auto request = [&](int i) -> u32x4 {                                 // pair (i, i + 1); i differs between the lanes of a wave (strips)
-        const int y = i + rb;
-        const bool ok = colok && (unsigned)y < (unsigned)H;
-        const uint32_t off = ok ? (uint32_t)y * (uint32_t)W + colofs : OUTSIDE;
-        return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
-    };
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    // Offsets are plain 32-bit arithmetic, no selects: a row above the image gives a "negative" offset, i.e.
+    // one near 2^32, a row below it one at or beyond the frame's size, and the bounds check answers both with
+    // zeros; lanes without a valid chunk (units past the last one, chunks right of the row) read somewhere
+    // inside the frame and their values are masked or never stored.
+    const uint32_t W2 = 2u * (uint32_t)W;
     auto operand = [&](u32x4 p) -> v4i {
         if (edge_wave) {                                                 // wave-uniform
             if (sh == 1) p = u32x4{0u, p.x, p.y, p.z};
@@ -307,29 +313,46 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
     // they are used, into slots whose roles rotate: the loop body exists once per slot, so no register is copied
     // when the rows move up (a copy would have to wait for its load), and there is no guard inside a round (with
     // one the compiler copies the slots at the loop's end).
+    // The compiler counts memory operations to place its waits (loads and stores share one in-order counter)
+    // and takes the smallest count over every path into the loop; coming from the prologue only the requests
+    // are in flight, which would make the wait before a pair's first use wait for the younger request as well.
+    // The prologue therefore waits for its own requests (once per wave): the loop is then entered with nothing
+    // pending and its waits are the ones its own back edge needs -- the younger requests and stores stay in
+    // flight.  (Peeling the first round off instead makes the compiler rotate the request registers with copies
+    // at the loop's end, and a copy waits for a load that has only just been issued.)
     const int npairs = (rows + 1) >> 1;
-    const int yrow = rb;                                                 // this lane's row inside a finished pair
+    // a lane stores row rel = 2 (step - DMAX) + rb of its strip while rel < len (unsigned: rel < 0 is a large number)
+    const uint32_t len = qok ? (uint32_t)(ye - ys) : 0u;
 
     if constexpr (ROLE == 0) {
         constexpr int DMAX = dmax<3, 0>();
         BlurState<3> s3;
         load_frags<3>(s3, lane);
-        const int i0 = ys - DMAX, n = npairs + DMAX;
+        const int n = npairs + DMAX;
+        uint32_t roff = (uint32_t)((ys - DMAX + rb) * W) + (colok ? (uint32_t)(col0 + 4 * sh) : 0u);   // next request
+        // the step that takes input pair i finishes output pair i - DMAX: the first one ys - 2 DMAX
+        uint32_t soff = ((uint32_t)((ys - 2 * DMAX + rb) * W4) + (uint32_t)q) * 16u + 12u;              // G3 dword of the row finished next
+        uint32_t rel = (uint32_t)(rb - 2 * DMAX);
         u32x4 R[AHEAD];
 #pragma unroll
-        for (int k = 0; k < AHEAD; k++) R[k] = request(i0 + 2 * k);
-        auto body = [&](int t, auto slot) {
+        for (int k = 0; k < AHEAD; k++) {
+            R[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)roff, 0, 0);
+            roff += W2;
+        }
+#pragma unroll
+        for (int k = 0; k < AHEAD; k++) use_now(R[k]);                   // a use: the compiler waits for the requests here
+        auto body = [&](auto slot) {
             constexpr int k = decltype(slot)::value;
-            const int i = i0 + 2 * t;
             const v4i P = operand(R[k]);
-            R[k] = request(i + 2 * AHEAD);
+            R[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)roff, 0, 0);
+            roff += W2;
             slide_mfma<3>(s3, P);
-            const int y3 = i - DMAX + yrow;                              // the G3 pair (i - 10, i - 9) is finished
-            const bool st_ok = qok && y3 >= ys && y3 < ye;
-            __builtin_amdgcn_raw_buffer_store_b32(finished_row<3>(s3) & gmask, ws, st_ok ? (int)(((uint32_t)y3 * (uint32_t)W4 + (uint32_t)q) * 16u + 12u) : (int)OUTSIDE, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(finished_row<3>(s3) & gmask, ws, rel < len ? (int)soff : (int)OUTSIDE, 0, 0);
+            soff += 4u * W2;                                           // two rows of W4 groups of 16 bytes
+            rel += 2u;
         };
         for (int t = 0; t < n; t += AHEAD)
-            static_for<0, AHEAD>([&](auto slot) { body(t + decltype(slot)::value, slot); });
+            static_for<0, AHEAD>([&](auto slot) { body(slot); });
     } else {
         constexpr int DMAX = dmax<2, 0>(), LAG = (dmax<2, 0>() - dmax<1, 0>()) / 2;   // G1 pairs wait LAG steps for their G2 pair
         static_assert(LAG == 2, "delay line of the 5x5 table's rows");
@@ -338,38 +361,45 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
         load_frags<2>(s2, lane);
         load_frags<1>(s1, lane);
         uint32_t d1[LAG] = {0, 0};
-        const int i0 = ys - DMAX, n = npairs + DMAX;
-        auto request_src = [&](int i) -> uint32_t {
-            const int y2 = i - DMAX + yrow;
-            const bool ok = qok && y2 >= ys && y2 < ye;
-            return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (int)((uint32_t)y2 * (uint32_t)W + 4u * (uint32_t)q) : (int)OUTSIDE, 0, 0);
-        };
+        const int n = npairs + DMAX;
+        uint32_t roff = (uint32_t)((ys - DMAX + rb) * W) + (colok ? (uint32_t)(col0 + 4 * sh) : 0u);
+        uint32_t srcoff = (uint32_t)((ys - 2 * DMAX + rb) * W) + 4u * (uint32_t)q;   // source dword of the row finished by the step requested next
+        uint32_t soff = ((uint32_t)((ys - 2 * DMAX + rb) * W4) + (uint32_t)q) * 16u;
+        uint32_t rel = (uint32_t)(rb - 2 * DMAX);
         u32x4 R[AHEAD];
         uint32_t S[AHEAD];
 #pragma unroll
         for (int k = 0; k < AHEAD; k++) {
-            R[k] = request(i0 + 2 * k);
-            S[k] = request_src(i0 + 2 * k);
+            R[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)roff, 0, 0);
+            S[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)srcoff, 0, 0);
+            roff += W2;
+            srcoff += W2;
         }
-        auto body = [&](int t, auto slot) {
+#pragma unroll
+        for (int k = 0; k < AHEAD; k++) { use_now(R[k]); use_now(S[k]); }
+        auto body = [&](auto slot) {
             constexpr int k = decltype(slot)::value;
-            const int i = i0 + 2 * t;
             const v4i P = operand(R[k]);
-            const uint32_t sp = S[k];
-            R[k] = request(i + 2 * AHEAD);
-            S[k] = request_src(i + 2 * AHEAD);
+            // the G2 pair (i - 6, i - 5) and the G1 pair (i - 2, i - 1) are finished by this step.  The source dword
+            // leaves first, from the register its load wrote, before that register is requested again (as part of one
+            // 12-byte store it would need a copy into a register next to the others, and the copy would wait for a
+            // load that has only just been issued)
+            const uint32_t so = rel < len ? soff : OUTSIDE;
+            __builtin_amdgcn_raw_buffer_store_b32(S[k], ws, (int)so, 0, 0);
+            R[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)roff, 0, 0);
+            S[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)srcoff, 0, 0);
+            roff += W2;
+            srcoff += W2;
             slide_mfma<2>(s2, P);
             slide_mfma<1>(s1, P);
-            const int y2 = i - DMAX + yrow;                              // the G2 pair (i - 6, i - 5) and the G1 pair (i - 2, i - 1) are finished
-            const bool st_ok = qok && y2 >= ys && y2 < ye;
-            typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
-            __builtin_amdgcn_raw_buffer_store_b96(u32x3{sp, d1[LAG - 1] & gmask, finished_row<2>(s2) & gmask}, ws,
-                                                  st_ok ? (int)(((uint32_t)y2 * (uint32_t)W4 + (uint32_t)q) * 16u) : (int)OUTSIDE, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{d1[LAG - 1] & gmask, finished_row<2>(s2) & gmask}, ws, (int)so, 4, 0);   // scalar offset 4: the G1 and G2 dwords
+            soff += 4u * W2;                                           // two rows of W4 groups of 16 bytes
+            rel += 2u;
             d1[1] = d1[0];
             d1[0] = finished_row<1>(s1);
         };
         for (int t = 0; t < n; t += AHEAD)
-            static_for<0, AHEAD>([&](auto slot) { body(t + decltype(slot)::value, slot); });
+            static_for<0, AHEAD>([&](auto slot) { body(slot); });
     }
 }
 
