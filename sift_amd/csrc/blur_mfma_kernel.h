@@ -172,6 +172,12 @@ constexpr bool frags_hold_the_table()
 }
 static_assert(frags_hold_the_table<1>() && frags_hold_the_table<2>() && frags_hold_the_table<3>(), "fragments = tables");
 
+#ifndef BLUR_STORE_AUX
+#define BLUR_STORE_AUX 0     // cache policy bits of the pyr stores (bit 0 sc0, bit 1 nt, bit 4 sc1)
+#endif
+#ifndef BLUR_MFMA_WAVES
+#define BLUR_MFMA_WAVES 2
+#endif
 #ifndef BLUR_MFMA_AHEAD
 #define BLUR_MFMA_AHEAD 2
 #endif
@@ -295,7 +301,17 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
     // one near 2^32, a row below it one at or beyond the frame's size, and the bounds check answers both with
     // zeros; lanes without a valid chunk (units past the last one, chunks right of the row) read somewhere
     // inside the frame and their values are masked or never stored.
+#ifdef BLUR_EXP_HOTLOAD
+    const uint32_t W2 = 0u;    // timing only: every request reads the same pair of rows
+#else
     const uint32_t W2 = 2u * (uint32_t)W;
+#endif
+#ifdef BLUR_EXP_NARROWLOAD
+    // timing only: a request is 4 bytes per lane (a quarter of the L1 requests), the operand its four copies
+    auto REQ = [&](uint32_t off) -> u32x4 { const uint32_t d = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(off & ~15u) + 4 * (lane & 3), 0, 0); return u32x4{d, d, d, d}; };
+#else
+    auto REQ = [&](uint32_t off) -> u32x4 { return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0); };
+#endif
     auto operand = [&](u32x4 p) -> v4i {
         if (edge_wave) {                                                 // wave-uniform
             if (sh == 1) p = u32x4{0u, p.x, p.y, p.z};
@@ -322,7 +338,16 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
     // at the loop's end, and a copy waits for a load that has only just been issued.)
     const int npairs = (rows + 1) >> 1;
     // a lane stores row rel = 2 (step - DMAX) + rb of its strip while rel < len (unsigned: rel < 0 is a large number)
+#ifdef BLUR_EXP_HOTSTORE
+#define BLUR_SOFF(x) ((x) & 0xfffffu)     // timing only: every store lands in the frame's first megabyte (stays in the L2)
+#else
+#define BLUR_SOFF(x) (x)
+#endif
+#ifdef BLUR_EXP_NOSTORE
+    const uint32_t len = 0u;   // timing only: nothing is stored
+#else
     const uint32_t len = qok ? (uint32_t)(ye - ys) : 0u;
+#endif
 
     if constexpr (ROLE == 0) {
         constexpr int DMAX = dmax<3, 0>();
@@ -331,12 +356,17 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
         const int n = npairs + DMAX;
         uint32_t roff = (uint32_t)((ys - DMAX + rb) * W) + (colok ? (uint32_t)(col0 + 4 * sh) : 0u);   // next request
         // the step that takes input pair i finishes output pair i - DMAX: the first one ys - 2 DMAX
+#ifdef BLUR_EXP_SEQSTORE
+        // timing only: every wave writes one sequential stream (1 KB per step)
+        uint32_t soff = ((uint32_t)group * (uint32_t)npairs - (uint32_t)DMAX) * 1024u + (uint32_t)lane * 16u + 12u;
+#else
         uint32_t soff = ((uint32_t)((ys - 2 * DMAX + rb) * W4) + (uint32_t)q) * 16u + 12u;              // G3 dword of the row finished next
+#endif
         uint32_t rel = (uint32_t)(rb - 2 * DMAX);
         u32x4 R[AHEAD];
 #pragma unroll
         for (int k = 0; k < AHEAD; k++) {
-            R[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)roff, 0, 0);
+            R[k] = REQ(roff);
             roff += W2;
         }
 #pragma unroll
@@ -344,11 +374,19 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
         auto body = [&](auto slot) {
             constexpr int k = decltype(slot)::value;
             const v4i P = operand(R[k]);
-            R[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)roff, 0, 0);
+            R[k] = REQ(roff);
             roff += W2;
             slide_mfma<3>(s3, P);
-            __builtin_amdgcn_raw_buffer_store_b32(finished_row<3>(s3) & gmask, ws, rel < len ? (int)soff : (int)OUTSIDE, 0, 0);
+#ifdef BLUR_EXP_FULLSTORE
+            asm volatile("" :: "v"(finished_row<3>(s3) & gmask));        // timing only: role 1 stores 16 bytes, this role nothing
+#else
+            __builtin_amdgcn_raw_buffer_store_b32(finished_row<3>(s3) & gmask, ws, rel < len ? (int)BLUR_SOFF(soff) : (int)OUTSIDE, 0, BLUR_STORE_AUX);
+#endif
+#ifdef BLUR_EXP_SEQSTORE
+            soff += 1024u;
+#else
             soff += 4u * W2;                                           // two rows of W4 groups of 16 bytes
+#endif
             rel += 2u;
         };
         for (int t = 0; t < n; t += AHEAD)
@@ -362,15 +400,24 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
         load_frags<1>(s1, lane);
         uint32_t d1[LAG] = {0, 0};
         const int n = npairs + DMAX;
+#ifdef BLUR_EXP_PRIVLOAD
+        // timing only: this role reads other lines than role 0 of its group (half a frame further down)
+        uint32_t roff = (uint32_t)(((ys - DMAX + rb + H / 2) % H) * W) + (colok ? (uint32_t)(col0 + 4 * sh) : 0u);
+#else
         uint32_t roff = (uint32_t)((ys - DMAX + rb) * W) + (colok ? (uint32_t)(col0 + 4 * sh) : 0u);
+#endif
         uint32_t srcoff = (uint32_t)((ys - 2 * DMAX + rb) * W) + 4u * (uint32_t)q;   // source dword of the row finished by the step requested next
+#ifdef BLUR_EXP_SEQSTORE
+        uint32_t soff = ((uint32_t)group * (uint32_t)npairs - (uint32_t)DMAX) * 1024u + (uint32_t)lane * 16u;
+#else
         uint32_t soff = ((uint32_t)((ys - 2 * DMAX + rb) * W4) + (uint32_t)q) * 16u;
+#endif
         uint32_t rel = (uint32_t)(rb - 2 * DMAX);
         u32x4 R[AHEAD];
         uint32_t S[AHEAD];
 #pragma unroll
         for (int k = 0; k < AHEAD; k++) {
-            R[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)roff, 0, 0);
+            R[k] = REQ(roff);
             S[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)srcoff, 0, 0);
             roff += W2;
             srcoff += W2;
@@ -384,16 +431,26 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
             // leaves first, from the register its load wrote, before that register is requested again (as part of one
             // 12-byte store it would need a copy into a register next to the others, and the copy would wait for a
             // load that has only just been issued)
-            const uint32_t so = rel < len ? soff : OUTSIDE;
-            __builtin_amdgcn_raw_buffer_store_b32(S[k], ws, (int)so, 0, 0);
-            R[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)roff, 0, 0);
+            const uint32_t so = rel < len ? BLUR_SOFF(soff) : OUTSIDE;
+#ifndef BLUR_EXP_FULLSTORE
+            __builtin_amdgcn_raw_buffer_store_b32(S[k], ws, (int)so, 0, BLUR_STORE_AUX);
+#endif
+            R[k] = REQ(roff);
             S[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)srcoff, 0, 0);
             roff += W2;
             srcoff += W2;
             slide_mfma<2>(s2, P);
             slide_mfma<1>(s1, P);
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{d1[LAG - 1] & gmask, finished_row<2>(s2) & gmask}, ws, (int)so, 4, 0);   // scalar offset 4: the G1 and G2 dwords
+#ifdef BLUR_EXP_FULLSTORE
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{d1[0] ^ d1[1], d1[LAG - 1] & gmask, finished_row<2>(s2) & gmask, d1[0]}, ws, (int)so, 0, 0);
+#else
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{d1[LAG - 1] & gmask, finished_row<2>(s2) & gmask}, ws, (int)so, 4, BLUR_STORE_AUX);   // scalar offset 4: the G1 and G2 dwords
+#endif
+#ifdef BLUR_EXP_SEQSTORE
+            soff += 1024u;
+#else
             soff += 4u * W2;                                           // two rows of W4 groups of 16 bytes
+#endif
             rel += 2u;
             d1[1] = d1[0];
             d1[0] = finished_row<1>(s1);
@@ -403,7 +460,7 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
     }
 }
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BLUR_MFMA_WAVES, BLUR_MFMA_WAVES)))
 void k_blur_mfma(const uint8_t *__restrict__ imgs, uint4 *__restrict__ pyr, int W, int H, int rows, int nstrips, int Wl)
 {
     // a workgroup of 128 g threads takes g unit groups: its first g waves run role 0, the other g role 1
