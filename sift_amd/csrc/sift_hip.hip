@@ -462,7 +462,7 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
         const int waves = (NB * nstrips + 15) / 16;
         // workgroups of two unit groups (two waves of each role; two workgroups fill a CU's register file):
         // measured against one and four groups per workgroup, 1.42 - 1.49 ms against 1.52 and 1.54 - 1.61 per 256 frames
-        hipLaunchKernelGGL(sift::k_blur_mfma, dim3((waves + 1) / 2, nframes), dim3(256), 0, s, d_imgs, c->d_pyr, W, H, rows, nstrips, c->Wl);
+        hipLaunchKernelGGL(sift::k_blur_mfma, dim3((waves + BLUR_MFMA_WG_GROUPS - 1) / BLUR_MFMA_WG_GROUPS, nframes), dim3(128 * BLUR_MFMA_WG_GROUPS), 0, s, d_imgs, c->d_pyr, W, H, rows, nstrips, c->Wl);
     } else {
         StageTimer t(c, ST_BLUR, s);
         const int rows = pick_blur_rows(c, nframes);
