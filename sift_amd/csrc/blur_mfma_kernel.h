@@ -309,12 +309,6 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
 #else
     const uint32_t W2 = 2u * (uint32_t)W;
 #endif
-#ifdef BLUR_EXP_NARROWLOAD
-    // timing only: a request is 4 bytes per lane (a quarter of the L1 requests), the operand its four copies
-    auto REQ = [&](uint32_t off) -> u32x4 { const uint32_t d = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(off & ~15u) + 4 * (lane & 3), 0, 0); return u32x4{d, d, d, d}; };
-#else
-    auto REQ = [&](uint32_t off) -> u32x4 { return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0); };
-#endif
     auto operand = [&](u32x4 p) -> v4i {
         if (edge_wave) {                                                 // wave-uniform
             if (sh == 1) p = u32x4{0u, p.x, p.y, p.z};
@@ -359,17 +353,12 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
         const int n = npairs + DMAX;
         uint32_t roff = (uint32_t)((ys - DMAX + rb) * W) + (colok ? (uint32_t)(col0 + 4 * sh) : 0u);   // next request
         // the step that takes input pair i finishes output pair i - DMAX: the first one ys - 2 DMAX
-#ifdef BLUR_EXP_SEQSTORE
-        // timing only: every wave writes one sequential stream (1 KB per step)
-        uint32_t soff = ((uint32_t)group * (uint32_t)npairs - (uint32_t)DMAX) * 1024u + (uint32_t)lane * 16u + 12u;
-#else
         uint32_t soff = ((uint32_t)((ys - 2 * DMAX + rb) * W4) + (uint32_t)q) * 16u + 12u;              // G3 dword of the row finished next
-#endif
         uint32_t rel = (uint32_t)(rb - 2 * DMAX);
         u32x4 R[AHEAD];
 #pragma unroll
         for (int k = 0; k < AHEAD; k++) {
-            R[k] = REQ(roff);
+            R[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)roff, 0, 0);
             roff += W2;
         }
 #pragma unroll
@@ -377,19 +366,11 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
         auto body = [&](auto slot) {
             constexpr int k = decltype(slot)::value;
             const v4i P = operand(R[k]);
-            R[k] = REQ(roff);
+            R[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)roff, 0, 0);
             roff += W2;
             slide_mfma<3>(s3, P);
-#ifdef BLUR_EXP_FULLSTORE
-            asm volatile("" :: "v"(finished_row<3>(s3) & gmask));        // timing only: role 1 stores 16 bytes, this role nothing
-#else
             __builtin_amdgcn_raw_buffer_store_b32(finished_row<3>(s3) & gmask, ws, rel < len ? (int)BLUR_SOFF(soff) : (int)OUTSIDE, 0, BLUR_STORE_AUX);
-#endif
-#ifdef BLUR_EXP_SEQSTORE
-            soff += 1024u;
-#else
             soff += 4u * W2;                                           // two rows of W4 groups of 16 bytes
-#endif
             rel += 2u;
         };
         for (int t = 0; t < n; t += AHEAD)
@@ -403,24 +384,15 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
         load_frags<1>(s1, lane);
         uint32_t d1[LAG] = {0, 0};
         const int n = npairs + DMAX;
-#ifdef BLUR_EXP_PRIVLOAD
-        // timing only: this role reads other lines than role 0 of its group (half a frame further down)
-        uint32_t roff = (uint32_t)(((ys - DMAX + rb + H / 2) % H) * W) + (colok ? (uint32_t)(col0 + 4 * sh) : 0u);
-#else
         uint32_t roff = (uint32_t)((ys - DMAX + rb) * W) + (colok ? (uint32_t)(col0 + 4 * sh) : 0u);
-#endif
         uint32_t srcoff = (uint32_t)((ys - 2 * DMAX + rb) * W) + 4u * (uint32_t)q;   // source dword of the row finished by the step requested next
-#ifdef BLUR_EXP_SEQSTORE
-        uint32_t soff = ((uint32_t)group * (uint32_t)npairs - (uint32_t)DMAX) * 1024u + (uint32_t)lane * 16u;
-#else
         uint32_t soff = ((uint32_t)((ys - 2 * DMAX + rb) * W4) + (uint32_t)q) * 16u;
-#endif
         uint32_t rel = (uint32_t)(rb - 2 * DMAX);
         u32x4 R[AHEAD];
         uint32_t S[AHEAD];
 #pragma unroll
         for (int k = 0; k < AHEAD; k++) {
-            R[k] = REQ(roff);
+            R[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)roff, 0, 0);
             S[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)srcoff, 0, 0);
             roff += W2;
             srcoff += W2;
@@ -435,170 +407,21 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
             // 12-byte store it would need a copy into a register next to the others, and the copy would wait for a
             // load that has only just been issued)
             const uint32_t so = rel < len ? BLUR_SOFF(soff) : OUTSIDE;
-#ifndef BLUR_EXP_FULLSTORE
             __builtin_amdgcn_raw_buffer_store_b32(S[k], ws, (int)so, 0, BLUR_STORE_AUX);
-#endif
-            R[k] = REQ(roff);
+            R[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)roff, 0, 0);
             S[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)srcoff, 0, 0);
             roff += W2;
             srcoff += W2;
             slide_mfma<2>(s2, P);
             slide_mfma<1>(s1, P);
-#ifdef BLUR_EXP_FULLSTORE
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{d1[0] ^ d1[1], d1[LAG - 1] & gmask, finished_row<2>(s2) & gmask, d1[0]}, ws, (int)so, 0, 0);
-#else
             __builtin_amdgcn_raw_buffer_store_b64(u32x2{d1[LAG - 1] & gmask, finished_row<2>(s2) & gmask}, ws, (int)so, 4, BLUR_STORE_AUX);   // scalar offset 4: the G1 and G2 dwords
-#endif
-#ifdef BLUR_EXP_SEQSTORE
-            soff += 1024u;
-#else
             soff += 4u * W2;                                           // two rows of W4 groups of 16 bytes
-#endif
             rel += 2u;
             d1[1] = d1[0];
             d1[0] = finished_row<1>(s1);
         };
         for (int t = 0; t < n; t += AHEAD)
             static_for<0, AHEAD>([&](auto slot) { body(slot); });
-    }
-}
-
-// ---- the same work with the two roles as producer and consumer of the memory traffic ---------------------------
-// Loads and stores of a wave share one in-order counter, so a wave that does both cannot take a row pair out of
-// its request registers before every older store has been acknowledged: measured (timing only), the kernel above
-// takes 1.10 ms per 256 frames, 0.70 without its stores, 0.56 with stores but every request hitting the L1, 0.54
-// with neither -- the matrix cores' time.  Here no wave does both:
-//   * role 0 requests the row pairs (the only loads of the workgroup), hands each operand P(s) to role 1 through
-//     an LDS ring, runs the 19x19 table and hands the finished G3 dwords over the same way; it never stores;
-//   * role 1 takes P(s - 1) from the ring, runs the 11x11 and 5x5 tables and stores whole 16-byte groups
-//     {src, G1, G2, G3} -- src is a dword of the P of six steps ago, G1 and G2 wait in a ring of its own until
-//     the G3 of their rows has arrived; it never loads from global memory, so it never waits for its stores.
-// One s_barrier per step orders the two (without the full memory wait of __syncthreads, which would end role 0's
-// prefetch): what role 0 writes in step s is read in step s + 1.  Every wave of the workgroup runs the same number
-// of steps, waves of a group past the last one included (they only meet the barriers).
-constexpr int BM_RING = 8;        // P ring: role 1 reads slots s - 1 and s - 6 while role 0 writes slot s
-constexpr int BM_STORE_LAG = 11;  // role 1 stores pair s - 11 in step s (role 0 finished it in step s - 1)
-
-struct BlurLds {
-    uint4 p[2][BM_RING][64];      // [group of the workgroup][slot][lane]: operands
-    uint32_t g3[2][2][64];        // finished G3 dwords of role 0
-    uint2 g12[2][BM_RING][64];    // role 1's own finished {G1, G2} dwords
-};
-
-__device__ __forceinline__ void blur_step_barrier()
-{
-    // LDS writes of this step have to be done before the other role reads them; no wait for global memory
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <int ROLE>
-__device__ __forceinline__ void blur_mfma_split_role(const uint8_t *__restrict__ imgs, uint4 *__restrict__ pyr, int W, int H, int rows,
-                                                     int nstrips, int group, int gi, int lane, int Wl, BlurLds &lds, bool gvalid)
-{
-    constexpr int AHEAD = BLUR_MFMA_AHEAD;
-    constexpr int DMAX3 = dmax<3, 0>(), DMAX2 = dmax<2, 0>(), DMAX1 = dmax<1, 0>();
-    static_assert(BM_STORE_LAG == DMAX3 + 1 && (BM_RING & (BM_RING - 1)) == 0 && BM_RING > (DMAX3 + 2) / 2, "ring depths");
-    const int W4 = W >> 2, NB = blur_mfma_blocks(W);
-    const int u = group * 16 + (lane & 15), g = lane >> 4;
-    const bool uvalid = gvalid && u < NB * nstrips;
-    const int strip = uvalid ? u / NB : 0, xb = uvalid ? u - strip * NB : 0;
-    const int ys = strip * rows, ye = min(H, ys + rows);
-    const size_t fofs = (size_t)blockIdx.y * (size_t)W * (size_t)H;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(imgs + fofs), 0, (int)((uint32_t)W * (uint32_t)H), 0x00020000);
-    const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(pyr + (fofs >> 2), 0, (int)((uint32_t)W * (uint32_t)H * 4u), 0x00020000);
-    constexpr uint32_t OUTSIDE = 0xfffffff0u;
-    const int rb = g >> 1;
-    const int col0 = BM_UNIT * xb - BM_LEFT + 16 * (g & 1);
-    const int sh = col0 < 0 ? (-col0) >> 2 : 0;
-    const int ndw = max(0, min(4, (W - col0) >> 2));
-    const bool colok = uvalid && ndw > 0;
-    const bool edge_wave = __any(sh != 0 || ndw < 4);
-    const int q = 2 * xb + (g & 1);
-    const bool qok = uvalid && q < W4;
-    const int inside = Wl - 4 * q;
-    const uint32_t gmask = inside >= 4 ? ~0u : inside <= 0 ? 0u : (1u << (8 * inside)) - 1u;
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-#ifdef BLUR_EXP_HOTLOAD
-    const uint32_t W2 = 0u;
-#else
-    const uint32_t W2 = 2u * (uint32_t)W;
-#endif
-    // every wave of the workgroup runs nsteps steps: role 1 stores the strip's last pair in step npairs - 1 + LAG
-    const int npairs = (rows + 1) >> 1;
-    const int nsteps = (npairs + BM_STORE_LAG + AHEAD - 1) / AHEAD * AHEAD;
-    if (!gvalid) {                                                       // wave-uniform: a group past the last one
-        for (int s = 0; s < nsteps; s++) blur_step_barrier();
-        return;
-    }
-
-    if constexpr (ROLE == 0) {
-        BlurState<3> s3;
-        load_frags<3>(s3, lane);
-        // step s takes input pair ys - 10 + 2 s and finishes output pair ys - 20 + 2 s
-        uint32_t roff = (uint32_t)((ys - DMAX3 + rb) * W) + (colok ? (uint32_t)(col0 + 4 * sh) : 0u);
-        u32x4 R[AHEAD];
-#pragma unroll
-        for (int k = 0; k < AHEAD; k++) {
-            R[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)roff, 0, 0);
-            roff += W2;
-        }
-#pragma unroll
-        for (int k = 0; k < AHEAD; k++) use_now(R[k]);                   // the loop is entered with nothing pending (see above)
-        auto body = [&](int s, auto slot) {
-            constexpr int k = decltype(slot)::value;
-            u32x4 p = R[k];
-            if (edge_wave) {                                             // wave-uniform
-                if (sh == 1) p = u32x4{0u, p.x, p.y, p.z};
-                if (sh == 3) p = u32x4{0u, 0u, 0u, p.x};
-                p.x = ndw > 0 ? p.x : 0u;
-                p.y = ndw > 1 ? p.y : 0u;
-                p.z = ndw > 2 ? p.z : 0u;
-                p.w = ndw > 3 ? p.w : 0u;
-            }
-            R[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)roff, 0, 0);
-            roff += W2;
-            const v4i P = v4i{(int)(p.x ^ 0x80808080u), (int)(p.y ^ 0x80808080u), (int)(p.z ^ 0x80808080u), (int)(p.w ^ 0x80808080u)};
-            lds.p[gi][s & (BM_RING - 1)][lane] = make_uint4((uint32_t)P[0], (uint32_t)P[1], (uint32_t)P[2], (uint32_t)P[3]);
-            slide_mfma<3>(s3, P);
-            lds.g3[gi][s & 1][lane] = finished_row<3>(s3) & gmask;
-            blur_step_barrier();
-        };
-        for (int s = 0; s < nsteps; s += AHEAD)
-            static_for<0, AHEAD>([&](auto slot) { body(s + decltype(slot)::value, slot); });
-    } else {
-        BlurState<2> s2;
-        BlurState<1> s1;
-        load_frags<2>(s2, lane);
-        load_frags<1>(s1, lane);
-        // step s takes the operand of role 0's step s - 1 = input pair ys - 12 + 2 s, which is the 11x11 table's pair
-        // ys - 6 + 2 (s - 3): this role is three of its own steps "late", finishes G2 pair ys - 18 + 2 s and G1 pair
-        // ys - 14 + 2 s, and stores pair ys - 22 + 2 s, whose G3 role 0 finished in step s - 1
-        static_assert(2 * (1 + DMAX3) == 2 * BM_STORE_LAG && DMAX3 - DMAX2 == 4 && DMAX3 - DMAX1 == 8, "delays of the rings below");
-#ifdef BLUR_EXP_NOSTORE
-        const uint32_t len = 0u;
-#else
-        const uint32_t len = qok ? (uint32_t)(ye - ys) : 0u;
-#endif
-        uint32_t soff = ((uint32_t)((ys - 2 * BM_STORE_LAG + 2 + rb) * W4) + (uint32_t)q) * 16u;   // of step 1, this role's first
-        uint32_t rel = (uint32_t)(rb - 2 * BM_STORE_LAG + 2);
-        const int srcdw = (g & 1) ? 0 : 3;                               // the lane's own four pixels inside its operand chunk
-        blur_step_barrier();                                             // role 0's step 0 (this role's first step is 1)
-        for (int s = 1; s < nsteps; s++) {
-            const uint4 pq = lds.p[gi][(s - 1) & (BM_RING - 1)][lane];
-            const v4i P = v4i{(int)pq.x, (int)pq.y, (int)pq.z, (int)pq.w};
-            // the source dword of the rows stored now: pair ys - 22 + 2 s was input pair of role 0's step s - 6
-            const uint32_t src = reinterpret_cast<const uint32_t *>(&lds.p[gi][(s - 6) & (BM_RING - 1)][lane])[srcdw] ^ 0x80808080u;
-            const uint32_t g3 = lds.g3[gi][(s - 1) & 1][lane];
-            slide_mfma<2>(s2, P);
-            slide_mfma<1>(s1, P);
-            lds.g12[gi][s & (BM_RING - 1)][lane] = make_uint2(finished_row<1>(s1) & gmask, finished_row<2>(s2) & gmask);
-            const uint32_t g2 = lds.g12[gi][(s - 2) & (BM_RING - 1)][lane].y;      // G2 pair ys - 18 + 2 (s - 2)
-            const uint32_t g1 = lds.g12[gi][(s - 4) & (BM_RING - 1)][lane].x;      // G1 pair ys - 14 + 2 (s - 4)
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{src, g1, g2, g3}, ws, rel < len ? (int)soff : (int)OUTSIDE, 0, 0);
-            soff += 8u * (uint32_t)W;
-            rel += 2u;
-            blur_step_barrier();
-        }
     }
 }
 
@@ -610,15 +433,9 @@ void k_blur_mfma(const uint8_t *__restrict__ imgs, uint4 *__restrict__ pyr, int 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = (int)blockDim.x >> 7;
     const int group = blockIdx.x * half + (wave % half);
     const bool gvalid = group * 16 < blur_mfma_blocks(W) * nstrips;     // wave-uniform
-#ifdef BLUR_MFMA_SPLIT
-    __shared__ BlurLds lds;
-    if (wave < half) blur_mfma_split_role<0>(imgs, pyr, W, H, rows, nstrips, group, wave % half, lane, Wl, lds, gvalid);
-    else blur_mfma_split_role<1>(imgs, pyr, W, H, rows, nstrips, group, wave % half, lane, Wl, lds, gvalid);
-#else
     if (!gvalid) return;
     if (wave < half) blur_mfma_role<0>(imgs, pyr, W, H, rows, nstrips, group, lane, Wl);
     else blur_mfma_role<1>(imgs, pyr, W, H, rows, nstrips, group, lane, Wl);
-#endif
 }
 
 }  // namespace sift

@@ -49,7 +49,25 @@
     X(35, "v_dot4_u32_u8 %0, %1, %2, %0\n\tv_add_u32 %0, %1, %0") \
     X(36, "v_dot4_u32_u8 %0, %1, %2, %0\n\tv_dot4_u32_u8 %0, %1, %2, %0\n\tv_dot4_u32_u8 %0, %1, %2, %0\n\tv_add_u32 %0, %1, %0") \
     X(37, "v_add_u32 %0, %1, %0\n\tv_lshlrev_b32 %0, 1, %0") \
-    X(38, "; v_lshl_add_u64 (two 32-bit adds in one)")
+    X(38, "; v_lshl_add_u64 (two 32-bit adds in one)") \
+    X(39, "v_pk_maximum3_f16 %0, %0, %1, %2") \
+    X(40, "v_pk_minimum3_f16 %0, %0, %1, %2") \
+    X(41, "v_pk_max_i16 %0, %0, %1") \
+    X(42, "v_pk_sub_i16 %0, %0, %1") \
+    X(43, "v_pk_add_f16 %0, %0, %1") \
+    X(44, "v_max3_i32 %0, %0, %1, %2") \
+    X(45, "v_sub_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1") \
+    X(46, "v_cmp_gt_f16_sdwa vcc, %0, %1 src0_sel:WORD_1 src1_sel:WORD_1") \
+    X(47, "v_cmp_gt_i32 vcc, %0, %1") \
+    X(48, "v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,1,0,0]") \
+    X(49, "v_dot2_i32_i16 %0, %1, %2, %0") \
+    X(50, "v_alignbit_b32 %0, %0, %1, 16") \
+    X(51, "v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf") \
+    X(52, "v_pk_lshrrev_b16 %0, 8, %0") \
+    X(53, "v_sqrt_f32 %0, %0") \
+    X(54, "v_cvt_f32_i32 %0, %0") \
+    X(55, "v_pk_max_f16 %0, %0, %1") \
+    X(56, "v_bitop3_b32 %0, %0, %1, %2 bitop3:0xc8")
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed)
