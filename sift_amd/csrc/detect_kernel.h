@@ -121,6 +121,39 @@ __device__ __forceinline__ uint32_t or8(uint32_t x)
     return x;
 }
 
+// ---- two pixels per instruction: packed binary16 --------------------------------------------------
+// The byte planes and their differences (|D| <= 255) are integers that binary16 holds exactly, and gfx950
+// has three-input packed maxima and minima (v_pk_maximum3_f16 / v_pk_minimum3_f16: one wave-instruction
+// per four cycles like every other VOP3, tools/ubench/valu_rate.hip), so the 26-neighbour test runs on
+// pairs of pixels.  A byte b enters as the half 0x6400 | b = 1024 + b (one v_perm_b32 per pair and plane);
+// the bias drops out of every difference.  Pairs are (pixel 0, pixel 2) = "even" and (pixel 1, pixel 3) =
+// "odd" of a lane's four pixels, low half first: the right-hand neighbours of the even pair are the odd pair
+// as it stands, the left-hand ones the odd pair moved up one half (v_alignbit with the neighbouring lane's).
+typedef uint32_t h2;
+constexpr uint32_t H2_BIAS = 0x64646464u;             // v_perm source: the exponent byte of 1024 + b
+constexpr uint32_t H2_SEL_EVEN = 0x04020400u;         // -> {0x64, byte 2, 0x64, byte 0}
+constexpr uint32_t H2_SEL_ODD = 0x04030401u;          // -> {0x64, byte 3, 0x64, byte 1}
+__device__ __forceinline__ h2 h2_sub(h2 a, h2 b) { h2 d; asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ h2 h2_max(h2 a, h2 b) { h2 d; asm("v_pk_max_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ h2 h2_min(h2 a, h2 b) { h2 d; asm("v_pk_min_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ h2 h2_max3(h2 a, h2 b, h2 c) { h2 d; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ h2 h2_min3(h2 a, h2 b, h2 c) { h2 d; asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// lane masks of a comparison of one half (HI = 0: low, 1: high) of two pairs; inactive lanes give 0
+template <int HI> __device__ __forceinline__ u64 h2_gt(h2 a, h2 b)
+{
+    u64 m;
+    if constexpr (HI) asm("v_cmp_gt_f16_sdwa %0, %1, %2 src0_sel:WORD_1 src1_sel:WORD_1" : "=s"(m) : "v"(a), "v"(b));
+    else asm("v_cmp_gt_f16_sdwa %0, %1, %2 src0_sel:WORD_0 src1_sel:WORD_0" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+template <int HI> __device__ __forceinline__ u64 h2_abs_ge(h2 a, h2 b)     // |a| >= b
+{
+    u64 m;
+    if constexpr (HI) asm("v_cmp_ge_f16_sdwa %0, |%1|, %2 src0_sel:WORD_1 src1_sel:WORD_1" : "=s"(m) : "v"(a), "v"(b));
+    else asm("v_cmp_ge_f16_sdwa %0, |%1|, %2 src0_sel:WORD_0 src1_sel:WORD_0" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+
 // D2 = G2 - G1 at (y, x) from the planar pyr plane, 0 outside the image.  Branch-free (clamped
 // address, masked result) so that the nine calls of one edge test load in parallel.
 __device__ __forceinline__ int pyr_d2_at(const uint4 *__restrict__ fp, int W4, int W, int H, int y, int x)
@@ -169,7 +202,10 @@ constexpr int DETECT_ROWS = 32;                       // most rows per strip (LD
 // entries (4 pixels x 64 lanes); when the next three rows might not fit the queue is drained (edge
 // test) in the middle of the strip, so no density of extrema can overflow it.  (A strict maximum and a strict minimum may be neighbours, so
 // "never 8-adjacent" bounds only each kind by 1/4; real frames stay near 1 %.)
-constexpr int DETECT_QUEUE = 256 * DETECT_ROWS / 4;
+#ifndef DETECT_QUEUE_ENTRIES
+#define DETECT_QUEUE_ENTRIES (256 * DETECT_ROWS / 4)
+#endif
+constexpr int DETECT_QUEUE = DETECT_QUEUE_ENTRIES;
 static_assert(DETECT_QUEUE >= 3 * 256, "three rows must fit after a drain");
 
 
@@ -199,7 +235,6 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
     const bool colvalid = g < W4;
     // halo column: the pixel left of the wave for lane 0, right of it for lane 63
     const int gh = lane == 0 ? g - 1 : g + 1;
-    const int hp = lane == 0 ? 3 : 0;                 // its pixel inside that group
 
     // A row is read through a buffer descriptor of exactly its W4 groups (none for rows outside the
     // image): lanes beyond the row, the halo lanes at the frame's left and right edge (offset -16
@@ -219,30 +254,35 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
         Qh = make_uint4(b.x, b.y, b.z, b.w);
     };
 
-    // Per column and row: e = max(D1, D3), f = min(D1, D3), b = D2.  Three rows are held (y-1, y,
-    // y+1) in three slots whose roles rotate: the loop body exists once per rotation phase, so no
-    // register is copied when the rows move up.
-    int se[3][4], sf[3][4], sb[3][4], he[3], hf[3], hb[3];
+    // Per pair of columns and row: e = max(D1, D3), f = min(D1, D3), m = max(D1, D2, D3), n = min(D1, D2, D3)
+    // and b = D2, as packed halves (even pair, odd pair).  Three rows are held (y-1, y, y+1) in three slots whose
+    // roles rotate: the loop body exists once per rotation phase, so no register is copied when the rows move up.
+    h2 se[3][2], sf[3][2], sm[3][2], sn[3][2], sb[3][2], hm[3], hn[3];
     uint32_t g2[3], hg2[3];                           // G2 dwords of the lane's group and of the halo group
-    auto stats = [&](const uint4 &Q, int p, int &e, int &f, int &b) {
-        const int d1 = byte_of(Q.y, p) - byte_of(Q.x, p);
-        const int d3 = byte_of(Q.w, p) - byte_of(Q.z, p);
-        b = byte_of(Q.z, p) - byte_of(Q.y, p);
-        e = max(d1, d3);
-        f = min(d1, d3);
-    };
+    // the halo pair: lane 0 needs pixel 3 of the group to its left (the odd pair's high half), lane 63 pixel 0 of
+    // the group to its right (the even pair's low half)
+    const uint32_t hsel = lane == 0 ? H2_SEL_ODD : H2_SEL_EVEN;
     // row r into slot k
     auto push = [&](const uint4 &Q, const uint4 &Qh, int k) {
+        const uint32_t sel[2] = {H2_SEL_EVEN, H2_SEL_ODD};
 #pragma unroll
-        for (int p = 0; p < 4; p++) stats(Q, p, se[k][p], sf[k][p], sb[k][p]);
-        // halo pixel: byte hp of each plane
-        const uint32_t sh = (uint32_t)hp * 8u;
-        const int hsrc = (int)((Qh.x >> sh) & 0xffu), h1 = (int)((Qh.y >> sh) & 0xffu);
-        const int h2 = (int)((Qh.z >> sh) & 0xffu), h3 = (int)((Qh.w >> sh) & 0xffu);
-        const int hd1 = h1 - hsrc, hd3 = h3 - h2;
-        hb[k] = h2 - h1;
-        he[k] = max(hd1, hd3);
-        hf[k] = min(hd1, hd3);
+        for (int j = 0; j < 2; j++) {
+            const h2 ps = __builtin_amdgcn_perm(H2_BIAS, Q.x, sel[j]), p1 = __builtin_amdgcn_perm(H2_BIAS, Q.y, sel[j]);
+            const h2 p2 = __builtin_amdgcn_perm(H2_BIAS, Q.z, sel[j]), p3 = __builtin_amdgcn_perm(H2_BIAS, Q.w, sel[j]);
+            const h2 d1 = h2_sub(p1, ps), d2 = h2_sub(p2, p1), d3 = h2_sub(p3, p2);
+            se[k][j] = h2_max(d1, d3);
+            sf[k][j] = h2_min(d1, d3);
+            sm[k][j] = h2_max3(d1, d2, d3);
+            sn[k][j] = h2_min3(d1, d2, d3);
+            sb[k][j] = d2;
+        }
+        {
+            const h2 ps = __builtin_amdgcn_perm(H2_BIAS, Qh.x, hsel), p1 = __builtin_amdgcn_perm(H2_BIAS, Qh.y, hsel);
+            const h2 p2 = __builtin_amdgcn_perm(H2_BIAS, Qh.z, hsel), p3 = __builtin_amdgcn_perm(H2_BIAS, Qh.w, hsel);
+            const h2 d1 = h2_sub(p1, ps), d2 = h2_sub(p2, p1), d3 = h2_sub(p3, p2);
+            hm[k] = h2_max3(d1, d2, d3);
+            hn[k] = h2_min3(d1, d2, d3);
+        }
         g2[k] = Q.z;
         hg2[k] = Qh.z;
     };
@@ -276,7 +316,10 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
         __syncthreads();
         qcount = 0;
     };
-    const int th1 = max(contrastTh, 1);               // |D2| >= contrastTh (:194) and |D2| != 0 (:684) in one test
+    // |D2| >= contrastTh (:194) and |D2| != 0 (:684) in one test; |D2| <= 255, so any threshold above 256 is 256
+    const uint32_t thbits = 0x6400u | (uint32_t)(min(max(contrastTh, 1), 256) & 0x3ff);               // 1024 + th ...
+    const h2 thh = h2_sub(thbits | thbits << 16, 0x64006400u);                                          // ... - 1024, both halves
+    const u64 colmask = __ballot(colvalid);
     // one image row; A, B, C = slots of rows y-1, y, y+1 (C is overwritten with row y+1)
     auto row = [&](int y, auto ka, auto kb, auto kc) {
         constexpr int A = decltype(ka)::value, B = decltype(kb)::value, C = decltype(kc)::value;
@@ -285,39 +328,30 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
                                                                          // three iterations ahead was measured: 1.3 % slower)
         push(Q, Qh, C);
 
-        // per column: max/min over the three rows
-        int E[4], F[4], BA[4], BI[4];
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            E[p] = max(max(se[A][p], se[B][p]), se[C][p]);
-            F[p] = min(min(sf[A][p], sf[B][p]), sf[C][p]);
-            BA[p] = max(max(sb[A][p], sb[B][p]), sb[C][p]);
-            BI[p] = min(min(sb[A][p], sb[B][p]), sb[C][p]);
-        }
-        const int hE = max(max(he[A], he[B]), he[C]), hF = min(min(hf[A], hf[B]), hf[C]);
-        const int hBA = max(max(hb[A], hb[B]), hb[C]), hBI = min(min(hb[A], hb[B]), hb[C]);
-        const int lE = from_left(hE, E[3]), lF = from_left(hF, F[3]);
-        const int lBA = from_left(hBA, BA[3]), lBI = from_left(hBI, BI[3]);
-        const int rE = from_right(hE, E[0]), rF = from_right(hF, F[0]);
-        const int rBA = from_right(hBA, BA[0]), rBI = from_right(hBI, BI[0]);
-
-        bool pre[4];
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int El = p ? E[p - 1] : lE, Er = p < 3 ? E[p + 1] : rE;
-            const int Fl = p ? F[p - 1] : lF, Fr = p < 3 ? F[p + 1] : rF;
-            const int BAl = p ? BA[p - 1] : lBA, BAr = p < 3 ? BA[p + 1] : rBA;
-            const int BIl = p ? BI[p - 1] : lBI, BIr = p < 3 ? BI[p + 1] : rBI;
-            const int c = sb[B][p];
-            const int mx = max(max(max(El, E[p]), Er), max(max(BAl, BAr), max(sb[A][p], sb[C][p])));
-            const int mn = min(min(min(Fl, F[p]), Fr), min(min(BIl, BIr), min(sb[A][p], sb[C][p])));
-            const int ac = c < 0 ? -c : c;
-            // strict 26-neighbour extremum (:245-304), |D2| >= contrastTh (:194), kpOut = |c| non-zero (:684)
-            pre[p] = colvalid & ((c > mx) | (c < mn)) & (ac >= th1);
-        }
-
-        // the lane masks of the four tests are scalar values already: no vector work to combine them
-        const u64 pm[4] = {__ballot(pre[0]), __ballot(pre[1]), __ballot(pre[2]), __ballot(pre[3])};
+        // Neighbourhood maximum of a pixel (the 26 values of :245-304): its own column without the centre,
+        // Y = max(e[y], m[y-1], m[y+1]), and the whole columns left and right of it, X = max(m[y-1], m[y], m[y+1]);
+        // minima alike.  The odd pair is the even pair's right-hand columns and the even pair the odd pair's
+        // left-hand ones; the other two come from the neighbouring lanes (halo pairs at the wave's ends).
+        const h2 XE = h2_max3(sm[A][0], sm[B][0], sm[C][0]), XO = h2_max3(sm[A][1], sm[B][1], sm[C][1]);
+        const h2 NE = h2_min3(sn[A][0], sn[B][0], sn[C][0]), NO = h2_min3(sn[A][1], sn[B][1], sn[C][1]);
+        const h2 hX = h2_max3(hm[A], hm[B], hm[C]), hN = h2_min3(hn[A], hn[B], hn[C]);
+        const h2 XlE = __builtin_amdgcn_alignbit(XO, (uint32_t)from_left((int)hX, (int)XO), 16);    // columns -1, 1
+        const h2 NlE = __builtin_amdgcn_alignbit(NO, (uint32_t)from_left((int)hN, (int)NO), 16);
+        const h2 XrO = __builtin_amdgcn_alignbit((uint32_t)from_right((int)hX, (int)XE), XE, 16);   // columns 2, 4
+        const h2 NrO = __builtin_amdgcn_alignbit((uint32_t)from_right((int)hN, (int)NE), NE, 16);
+        const h2 mxE = h2_max3(XlE, h2_max3(se[B][0], sm[A][0], sm[C][0]), XO);
+        const h2 mxO = h2_max3(XE, h2_max3(se[B][1], sm[A][1], sm[C][1]), XrO);
+        const h2 mnE = h2_min3(NlE, h2_min3(sf[B][0], sn[A][0], sn[C][0]), NO);
+        const h2 mnO = h2_min3(NE, h2_min3(sf[B][1], sn[A][1], sn[C][1]), NrO);
+        // strict 26-neighbour extremum (:245-304), |D2| >= contrastTh (:194), kpOut = |c| non-zero (:684): lane
+        // masks straight from the comparisons (pixel p: even pair low, odd low, even high, odd high)
+        const h2 cE = sb[B][0], cO = sb[B][1];
+        const u64 pm[4] = {
+            (h2_gt<0>(cE, mxE) | h2_gt<0>(mnE, cE)) & h2_abs_ge<0>(cE, thh) & colmask,
+            (h2_gt<0>(cO, mxO) | h2_gt<0>(mnO, cO)) & h2_abs_ge<0>(cO, thh) & colmask,
+            (h2_gt<1>(cE, mxE) | h2_gt<1>(mnE, cE)) & h2_abs_ge<1>(cE, thh) & colmask,
+            (h2_gt<1>(cO, mxO) | h2_gt<1>(mnO, cO)) & h2_abs_ge<1>(cO, thh) & colmask,
+        };
         if ((pm[0] | pm[1] | pm[2] | pm[3]) != 0ull) {
 #pragma unroll
             for (int p = 0; p < 4; p++) {
@@ -325,7 +359,7 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
                 if (bal) {
                     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    if (pre[p] && qcount + below < (uint32_t)DETECT_QUEUE) queue[qcount + below] = ((uint32_t)y << 16) | (uint32_t)(g * 4 + p);
+                    if (((bal >> lane) & 1ull) && qcount + below < (uint32_t)DETECT_QUEUE) queue[qcount + below] = ((uint32_t)y << 16) | (uint32_t)(g * 4 + p);
                     qcount += (uint32_t)__popcll(bal);
                 }
             }
