@@ -314,8 +314,9 @@ int sift_hip_set_graph_frames(sift_hip_ctx *ctx, int max_frames);
 int sift_hip_set_quad_sweep(sift_hip_ctx *ctx, int on);
 /* Tuning knob: rows per strip of the detect kernel (0 = heuristic; clamped to [4, 32]). */
 int sift_hip_set_detect_rows(sift_hip_ctx *ctx, int rows);
-/* Test knob: LDS queue entries the detect kernel fills before it drains the queue in the middle of a
- * strip (0 = the full queue, 2048; clamped to [768, 2048]).  Results do not depend on it. */
+/* Test knob: LDS queue entries the detect kernel may hold (0 = the full queue, 512; clamped to [256, 512]); it
+ * drains the queue in the middle of a strip after any row that leaves fewer than 256 of them free.  Results
+ * do not depend on it. */
 int sift_hip_set_detect_queue(sift_hip_ctx *ctx, int entries);
 
 #ifdef __cplusplus

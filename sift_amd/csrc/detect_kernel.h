@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include "blur_kernel.h"     // static_for
 
 namespace sift {
 
@@ -138,6 +139,13 @@ __device__ __forceinline__ h2 h2_max(h2 a, h2 b) { h2 d; asm("v_pk_max_f16 %0, %
 __device__ __forceinline__ h2 h2_min(h2 a, h2 b) { h2 d; asm("v_pk_min_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ h2 h2_max3(h2 a, h2 b, h2 c) { h2 d; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ h2 h2_min3(h2 a, h2 b, h2 c) { h2 d; asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ h2 h2_add(h2 a, h2 b) { h2 d; asm("v_pk_add_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// a + b - 2 c
+__device__ __forceinline__ h2 h2_second_diff(h2 a, h2 b, h2 c) { h2 d; asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(d) : "v"(c), "v"(0xc000c000u), "v"(h2_add(a, b))); return d; }
+// half HI of x in the low half, half HI of y in the high half of the result
+template <int HI> __device__ __forceinline__ uint32_t h2_pick(h2 x, h2 y) { return __builtin_amdgcn_perm(y, x, HI ? 0x07060302u : 0x05040100u); }
+__device__ __forceinline__ float h2_lo_float(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
+__device__ __forceinline__ float h2_hi_float(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
 // lane masks of a comparison of one half (HI = 0: low, 1: high) of two pairs; inactive lanes give 0
 template <int HI> __device__ __forceinline__ u64 h2_gt(h2 a, h2 b)
 {
@@ -186,6 +194,20 @@ __device__ __forceinline__ int edge_ratio_q15(int L, int R, int U, int Dn, int U
     return (int)fl + ((v - fl) > 0.5f ? 1 : 0);
 }
 
+// The same from the three second differences as exact binary32 integers (|fxx|, |fyy|, |fxy| <= 1020, so the trace
+// squared and the determinant stay below 2^24: every product and difference is exact, fused or not).
+__device__ __forceinline__ int edge_ratio_q15_f(float fxx, float fyy, float fxy)
+{
+    const float tr = fxx + fyy;
+    const float det = fxx * fyy - fxy * fxy;
+    if (det == 0.0f) return -1;
+    const float r = __fdiv_rn(tr * tr, det);
+    if (r < 0.0f || r > 12.0f) return -1;            // EIGEN_RATIO_TH, DetectKeypoints.hpp:18
+    const float v = r * 32768.0f;
+    const float fl = floorf(v);
+    return (int)fl + ((v - fl) > 0.5f ? 1 : 0);
+}
+
 // Q15 edge ratio of the pixel (y, x), -1 if the edge test rejects it; *contrast = |D2|
 __device__ __forceinline__ int edge_at(const uint4 *__restrict__ fp, int W4, int W, int H, int y, int x, int *contrast)
 {
@@ -198,15 +220,16 @@ __device__ __forceinline__ int edge_at(const uint4 *__restrict__ fp, int W4, int
 }
 
 constexpr int DETECT_ROWS = 32;                       // most rows per strip (LDS is sized for it)
-// LDS queue of the pixels that passed the extremum and contrast tests.  A row adds at most 256
-// entries (4 pixels x 64 lanes); when the next three rows might not fit the queue is drained (edge
-// test) in the middle of the strip, so no density of extrema can overflow it.  (A strict maximum and a strict minimum may be neighbours, so
-// "never 8-adjacent" bounds only each kind by 1/4; real frames stay near 1 %.)
+// LDS queue of the pixels that passed the extremum and contrast tests: position, the three second differences
+// of the edge test (:314-352) and D2 itself, 12 bytes.  A row adds at most 256 entries (4 pixels x 64 lanes); the
+// queue is drained (edge test) at the strip's end and after any row that leaves fewer than 256 free entries, so no
+// density of extrema can overflow it.  (A strict maximum and a strict minimum may be neighbours, so "never
+// 8-adjacent" bounds only each kind by 1/4; real frames stay near 1 %, about 80 entries per strip.)
 #ifndef DETECT_QUEUE_ENTRIES
-#define DETECT_QUEUE_ENTRIES (256 * DETECT_ROWS / 4)
+#define DETECT_QUEUE_ENTRIES 512
 #endif
 constexpr int DETECT_QUEUE = DETECT_QUEUE_ENTRIES;
-static_assert(DETECT_QUEUE >= 3 * 256, "three rows must fit after a drain");
+static_assert(DETECT_QUEUE >= 2 * 256, "a row must fit after a drain");
 
 
 // grid: x = ceil(W/256) spans, y = strips of `rows` <= DETECT_ROWS, z = frames; block = 64 (one wave)
@@ -217,7 +240,7 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
                                                uint16_t *__restrict__ gradp, uint32_t *__restrict__ gradfull,
                                                int W, int H, int S, int contrastTh, int rows, int qcap, int Wl)
 {
-    __shared__ uint32_t queue[DETECT_QUEUE];
+    __shared__ uint32_t queue[3][DETECT_QUEUE];       // [0]: y << 16 | x, [1]: fxx | fyy << 16, [2]: fxy | D2 << 16 (binary16)
     __shared__ u64 cmap[DETECT_ROWS * 4];             // candidate bits of the strip: row-major, 4 words per row
 
     const int lane = threadIdx.x;
@@ -245,11 +268,18 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
     // answers with zeros without a trip to the cache
     const uint32_t goff = (uint32_t)g * 16u, hoff = (lane == 0 || lane == 63) ? (uint32_t)gh * 16u : 0xfffffff0u;
     auto load_row = [&](int r, uint4 &Q, uint4 &Qh) {
+#ifdef DET_EXP_HOTLOAD
+        r = ys;                                                                  // timing only: every request reads the strip's first row
+#endif
         const bool in = r >= 0 && r < H;                                         // wave-uniform
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<uint4 *>(fp + (size_t)(in ? r : 0) * W4), 0, in ? W4 * 16 : 0, 0x00020000);
         const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)goff, 0, 0);
+#ifdef DET_EXP_NOHALO
+        const u32x4 b = a;                                                       // timing only
+#else
         const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)hoff, 0, 0);
+#endif
         Q = make_uint4(a.x, a.y, a.z, a.w);
         Qh = make_uint4(b.x, b.y, b.z, b.w);
     };
@@ -257,7 +287,10 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
     // Per pair of columns and row: e = max(D1, D3), f = min(D1, D3), m = max(D1, D2, D3), n = min(D1, D2, D3)
     // and b = D2, as packed halves (even pair, odd pair).  Three rows are held (y-1, y, y+1) in three slots whose
     // roles rotate: the loop body exists once per rotation phase, so no register is copied when the rows move up.
-    h2 se[3][2], sf[3][2], sm[3][2], sn[3][2], sb[3][2], hm[3], hn[3];
+    h2 se[3][2], sf[3][2], sm[3][2], sn[3][2], sb[3][2], hm[3], hn[3], hb[3];
+    // for the edge test (:314-352): the D2 pairs left of the even pair and right of the odd pair, and the horizontal
+    // differences left - right of both pairs (fxy = that of the row above minus that of the row below)
+    h2 bl[3], br[3], hd[3][2];
     uint32_t g2[3], hg2[3];                           // G2 dwords of the lane's group and of the halo group
     // the halo pair: lane 0 needs pixel 3 of the group to its left (the odd pair's high half), lane 63 pixel 0 of
     // the group to its right (the even pair's low half)
@@ -282,7 +315,13 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
             const h2 d1 = h2_sub(p1, ps), d2 = h2_sub(p2, p1), d3 = h2_sub(p3, p2);
             hm[k] = h2_max3(d1, d2, d3);
             hn[k] = h2_min3(d1, d2, d3);
+            hb[k] = d2;
         }
+        // (DPP shifts: every lane is active here)
+        bl[k] = __builtin_amdgcn_alignbit(sb[k][1], (uint32_t)from_left((int)hb[k], (int)sb[k][1]), 16);     // columns -1, 1
+        br[k] = __builtin_amdgcn_alignbit((uint32_t)from_right((int)hb[k], (int)sb[k][0]), sb[k][0], 16);    // columns 2, 4
+        hd[k][0] = h2_sub(bl[k], sb[k][1]);
+        hd[k][1] = h2_sub(sb[k][0], br[k]);
         g2[k] = Q.z;
         hg2[k] = Qh.z;
     };
@@ -298,16 +337,21 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
     uint2 gb0 = make_uint2(0u, 0u), gb1 = gb0, gb2 = gb0;   // gradient words of rows 4k .. 4k+2 until row 4k+3 is done
     uint32_t qcount = 0;                              // wave-uniform
     const size_t frow = (size_t)frame * H;
-    // Edge test on the queue, one lane per entry; what passes is a pre-cull candidate: its key and
-    // its bit in cmap are written.  Runs at the end of the strip and whenever the queue is nearly full after a row.
+    // Edge test on the queue, one lane per entry; what passes is a pre-cull candidate: its key and its bit in cmap
+    // are written.  Everything the test needs was queued from registers: no pixel is read again.
     auto drain = [&]() {
+#ifdef DET_EXP_NODRAIN
+        qcount = 0;                                                              // timing only: no edge test, no candidates
+        return;
+#endif
         __syncthreads();
         for (uint32_t i0 = 0; i0 < qcount; i0 += 64) {
             const bool live = i0 + lane < qcount;
-            const uint32_t e = live ? queue[i0 + lane] : 0u;
+            const uint32_t i = live ? i0 + lane : 0u;
+            const uint32_t e = queue[0][i], w1 = queue[1][i], w2 = queue[2][i];
             const int y = (int)(e >> 16), x = (int)(e & 0xffffu);
-            int ac;
-            const int ec = edge_at(fp, W4, W, H, y, x, &ac);
+            const int ec = edge_ratio_q15_f(h2_lo_float(w1), h2_hi_float(w1), h2_lo_float(w2));
+            const int ac = (int)fabsf(h2_hi_float(w2));
             if (live && ec >= 0) {                                       // :200
                 keyplane[fpix + (size_t)y * W + x] = ((uint32_t)ec << 8) | (uint32_t)ac;
                 atomicOr(&cmap[(y - ys) * 4 + ((x >> 6) & 3)], 1ull << (x & 63));
@@ -353,17 +397,27 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
             (h2_gt<1>(cO, mxO) | h2_gt<1>(mnO, cO)) & h2_abs_ge<1>(cO, thh) & colmask,
         };
         if ((pm[0] | pm[1] | pm[2] | pm[3]) != 0ull) {
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
+            // second differences of D2 at every pixel of the row (:318-322): fxx = L + R - 2c, fyy = U + Dn - 2c,
+            // fxy = UL + DR - DL - UR -- integers of at most 1020, exact in binary16
+            const h2 fxx[2] = {h2_second_diff(bl[B], sb[B][1], cE), h2_second_diff(sb[B][0], br[B], cO)};
+            const h2 fyy[2] = {h2_second_diff(sb[A][0], sb[C][0], cE), h2_second_diff(sb[A][1], sb[C][1], cO)};
+            const h2 fxy[2] = {h2_sub(hd[A][0], hd[C][0]), h2_sub(hd[A][1], hd[C][1])};
+            static_for<0, 4>([&](auto pp) {
+                constexpr int p = decltype(pp)::value, j = p & 1, hi = p >> 1;
                 const u64 bal = pm[p];
                 if (bal) {
                     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    if (((bal >> lane) & 1ull) && qcount + below < (uint32_t)DETECT_QUEUE) queue[qcount + below] = ((uint32_t)y << 16) | (uint32_t)(g * 4 + p);
+                    if (((bal >> lane) & 1ull) && qcount + below < (uint32_t)DETECT_QUEUE) {
+                        queue[0][qcount + below] = ((uint32_t)y << 16) | (uint32_t)(g * 4 + p);
+                        queue[1][qcount + below] = h2_pick<hi>(fxx[j], fyy[j]);
+                        queue[2][qcount + below] = h2_pick<hi>(fxy[j], sb[B][j]);
+                    }
                     qcount += (uint32_t)__popcll(bal);
                 }
-            }
+            });
         }
+        if (qcount + 256u > (uint32_t)qcap) drain();                     // wave-uniform: the next row might not fit
 
         // gradient of G2 at row y (:1189-1190): gx from the row itself, gy from rows y-1 and y+1
         // (the DPP shifts run with every lane active: a disabled source lane would leave `old`)
@@ -407,12 +461,19 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
             // stores its rows one by one); y, ys and ye are wave-uniform
             uint16_t *const gq = gradp + gradp_frame_words(W, H) * (size_t)frame;
             const int yr = y & 3;
+#ifdef DET_EXP_NOGRADSTORE
+            if (yr == 3 && y - 3 >= ys) {                                // timing only: the gradient words are computed, not stored
+                asm volatile("" :: "v"(gb0.x ^ gb0.y ^ gb1.x ^ gb1.y ^ gb2.x ^ gb2.y ^ o.x ^ o.y));
+            } else if (y - yr < ys || (y | 3) >= ye) {
+                asm volatile("" :: "v"(o.x ^ o.y));
+#else
             if (yr == 3 && y - 3 >= ys) {
                 uint4 *dst = reinterpret_cast<uint4 *>(gq + gradp_quad_word(y - 3, g, W4));
                 dst[0] = make_uint4(gb0.x, gb0.y, gb1.x, gb1.y);
                 dst[1] = make_uint4(gb2.x, gb2.y, o.x, o.y);
             } else if (y - yr < ys || (y | 3) >= ye) {
                 *reinterpret_cast<uint2 *>(gq + gradp_quad_word(y, g, W4)) = o;
+#endif
             } else if (yr == 0) {
                 gb0 = o;
             } else if (yr == 1) {
@@ -426,13 +487,11 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
         using K0 = std::integral_constant<int, 0>;
         using K1 = std::integral_constant<int, 1>;
         using K2 = std::integral_constant<int, 2>;
-        // after three rows at most 3 x 256 new entries: drain while that many may not fit (qcap is
-        // DETECT_QUEUE except in the test that forces drains, sift_hip_set_detect_queue)
+        // (qcap is DETECT_QUEUE except in the test that forces drains, sift_hip_set_detect_queue)
         for (int y = ys; y < ye; y += 3) {
             row(y, K0{}, K1{}, K2{});
             if (y + 1 < ye) row(y + 1, K1{}, K2{}, K0{});
             if (y + 2 < ye) row(y + 2, K2{}, K0{}, K1{});
-            if (qcount + 3u * 256u > (uint32_t)qcap) drain();
         }
     }
 

@@ -827,7 +827,7 @@ int sift_hip_set_detect_queue(sift_hip_ctx *c, int entries)
 {
     if (int r = check_ctx(c)) return r;
     if (entries < 0) return fail(SIFT_HIP_EINVAL, "entries must be >= 0");
-    c->detect_queue = entries == 0 ? (int)sift::DETECT_QUEUE : std::max(3 * 256, std::min(entries, (int)sift::DETECT_QUEUE));
+    c->detect_queue = entries == 0 ? (int)sift::DETECT_QUEUE : std::max(256, std::min(entries, (int)sift::DETECT_QUEUE));
     if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }   // a captured graph holds the old value
     c->gkey = sift_hip_ctx::GraphKey{};
     c->gseen = 0;

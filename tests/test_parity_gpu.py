@@ -585,7 +585,7 @@ def test_detect_queue_drains_in_mid_strip(sift, orc):
     """k_detect queues the pixels that pass the extremum and contrast tests in LDS and drains the
     queue when the next rows might not fit (a strict maximum and a strict minimum may be neighbours,
     so no density bound protects a fixed-size queue).  Noise at contrastTh = 0 with the smallest
-    queue forces a drain after almost every group of rows; every stage must still match the oracle."""
+    queue forces a drain after almost every row; every stage must still match the oracle."""
     rng = np.random.default_rng(17)
     H, W = 300, 520
     noise = rng.integers(0, 256, (H, W), dtype=np.uint8)
@@ -596,7 +596,7 @@ def test_detect_queue_drains_in_mid_strip(sift, orc):
             ref = orc.sift_detect(img, th, planes=True)
             n = nvalid(rk)
             with sift.SiftContext(W, H) as ctx:
-                for q in (768, 1000, 0):
+                for q in (256, 300, 0):
                     ctx.set_detect_queue(q)
                     kps, desc = ctx.sift_detect_and_compute(img, th)
                     assert (kps == rk).all() and (desc[:n] == rd[:n]).all() and not desc[n:].any(), (th, q)
@@ -604,7 +604,7 @@ def test_detect_queue_drains_in_mid_strip(sift, orc):
                     assert (pl["cand"] == ref["kp1"]).all() and (pl["surv"] == ref["kp2"]).all(), (th, q)
                     m = ref["kp1"] > 0
                     assert (pl["eratio"][m] == ref["eratio"][m]).all()
-            assert int((ref["kp1"] > 0).sum()) > 100                # with the smallest queue every group of rows that queued anything drains
+            assert int((ref["kp1"] > 0).sum()) > 100                # with the smallest queue every row that queued anything drains
 
 
 @pytest.mark.parametrize("W,H", [(640, 480), (324, 201), (148, 150), (1920, 1080), (36, 40), (4, 1)])
