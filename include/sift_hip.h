@@ -241,10 +241,13 @@ int sift_hip_gray_from_bgr_dev(sift_hip_ctx *ctx, const uint8_t *d_bgr, int nfra
  * Limit: sift_hip_static_scratch_needed(width, height, nframes) (about 10.3 bytes per pixel and
  * frame + 0.26 MB) must not exceed SIFT_HIP_STATIC_SCRATCH_BYTES -- one 1920x1080 frame or ten
  * 640x480 frames fit; larger calls fail with SIFT_HIP_EINVAL and a message that says so.
- * The first call on a device, and the first after the width changed, rebuilds the descriptor tables on
- * the host, copies them on `stream` and waits for that copy: make that call outside stream capture.
+ * A call for a frame width whose descriptor tables are not in the array builds them on the host, copies
+ * them on `stream` and waits for that copy: make such a call outside stream capture.  The tables of the two
+ * most recently used widths stay in the array, so only the first call for a width -- and calls that rotate
+ * through three or more widths -- pay that; everything else only enqueues.
  * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two
- * threads) race; order them on one stream or with events. */
+ * threads) race; order them on one stream or with events.  On the host, calls for one GPU are serialised by a
+ * lock of that GPU's own (held across the table copy's wait); calls for different GPUs do not wait for each other. */
 #define SIFT_HIP_STATIC_SCRATCH_BYTES (32u << 20)
 int sift_hip_detect_and_compute_static(int device, const uint8_t *d_imgs, int nframes, int width, int height,
                                        sift_keypoint *d_kps, uint32_t *d_desc, uint32_t *d_total, int contrastTh,

@@ -12,7 +12,7 @@
  * unbuildable here without writing stand-ins for them, which this project does
  * not do.  The only anchors are facts recorded in SURVEY.md from the survey's
  * own run of the reference: quantised-table sums/maxima/centre rows and the
- * keypoint counts of five named inputs (tests/test_oracle_pins.py checks them).
+ * keypoint counts of four named inputs (tests/test_oracle.py checks them).
  *
  * Every function cites the reference lines it restates (paths under
  * /root/reference/src).  All arithmetic is plain integer except one IEEE

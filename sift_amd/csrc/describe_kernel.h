@@ -143,6 +143,18 @@ __global__ __launch_bounds__(256) void k_grad_pairs(const uint4 *__restrict__ gr
     if (big) atomicOr(flag, huge ? 3u : 1u);
 }
 
+// The same check for planes that are swept in their own format (widths that are not a multiple of 4 skip
+// k_grad_pairs): a counted magnitude above 32767 raises both bits of *flag.  grid: blocks of 256, grid-stride.
+__global__ __launch_bounds__(256) void k_grad_check(const uint32_t *__restrict__ grad, uint32_t *__restrict__ flag, size_t n)
+{
+    bool huge = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint32_t g = grad[i], ang = g & 0xffffu;
+        huge |= ang >= 1u && ang <= 8u && (g >> 16) > 32767u;
+    }
+    if (huge) atomicOr(flag, 3u);
+}
+
 // grid: x = max_kp keypoints, y = frames; block = 64 (one wave)
 // NA, NU2, NU, NB > 0: the quad table has exactly NA, NU2, NU and NB steps of 64 entries (the reference's masks:
 // 5, 4, 1 and 2) and the sweep is straight-line code with every load of the window in flight at once
@@ -214,12 +226,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GFMT == 0 ? 
 
     {
         // hist = 0 with ds_write_addtid_b32 (address = M0 + offset + 4 * lane: no address register, 2 cycles per
-        // 256 bytes against 13 per 1024 for ds_write_b128).  Nothing else in this kernel uses M0.
+        // 256 bytes against 13 per 1024 for ds_write_b128).
         const uint32_t hist_lds = (uint32_t)(uintptr_t)&hist[0][0];   // low half of the flat address = LDS offset
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(hist_lds));   // an M0 write needs one wait state before an add-TID access
-        static_for<0, ROWS * 32 * 4 / 256>([&](auto i) {                 // the spare rows are never read: they need no clearing
-            asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(0u), "i"((int)decltype(i)::value * 256) : "memory");
-        });
+        // One asm statement for the M0 write and every store that reads it: the compiler has no place between them
+        // to put an M0 user of its own (indexed register moves, lane selects, LDS-direct); M0 is a reserved
+        // register that it sets anew before each of its own uses, so nothing of its own relies on the value left
+        // here (a clobber entry for it is refused as "reserved").  An M0 write needs one wait state before an
+        // add-TID access.
+        static_assert(ROWS * 32 * 4 / 256 == 20 || ROWS * 32 * 4 / 256 == 40, "the clears below");
+        if constexpr (ROWS * 32 * 4 / 256 == 20)                         // the spare rows are never read: they need no clearing
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                         "ds_write_addtid_b32 %1 offset:0\n\tds_write_addtid_b32 %1 offset:256\n\tds_write_addtid_b32 %1 offset:512\n\tds_write_addtid_b32 %1 offset:768\n\t"
+                         "ds_write_addtid_b32 %1 offset:1024\n\tds_write_addtid_b32 %1 offset:1280\n\tds_write_addtid_b32 %1 offset:1536\n\tds_write_addtid_b32 %1 offset:1792\n\t"
+                         "ds_write_addtid_b32 %1 offset:2048\n\tds_write_addtid_b32 %1 offset:2304\n\tds_write_addtid_b32 %1 offset:2560\n\tds_write_addtid_b32 %1 offset:2816\n\t"
+                         "ds_write_addtid_b32 %1 offset:3072\n\tds_write_addtid_b32 %1 offset:3328\n\tds_write_addtid_b32 %1 offset:3584\n\tds_write_addtid_b32 %1 offset:3840\n\t"
+                         "ds_write_addtid_b32 %1 offset:4096\n\tds_write_addtid_b32 %1 offset:4352\n\tds_write_addtid_b32 %1 offset:4608\n\tds_write_addtid_b32 %1 offset:4864"
+                         :: "s"(hist_lds), "v"(0u) : "memory");
+        else
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                         "ds_write_addtid_b32 %1 offset:0\n\tds_write_addtid_b32 %1 offset:256\n\tds_write_addtid_b32 %1 offset:512\n\tds_write_addtid_b32 %1 offset:768\n\t"
+                         "ds_write_addtid_b32 %1 offset:1024\n\tds_write_addtid_b32 %1 offset:1280\n\tds_write_addtid_b32 %1 offset:1536\n\tds_write_addtid_b32 %1 offset:1792\n\t"
+                         "ds_write_addtid_b32 %1 offset:2048\n\tds_write_addtid_b32 %1 offset:2304\n\tds_write_addtid_b32 %1 offset:2560\n\tds_write_addtid_b32 %1 offset:2816\n\t"
+                         "ds_write_addtid_b32 %1 offset:3072\n\tds_write_addtid_b32 %1 offset:3328\n\tds_write_addtid_b32 %1 offset:3584\n\tds_write_addtid_b32 %1 offset:3840\n\t"
+                         "ds_write_addtid_b32 %1 offset:4096\n\tds_write_addtid_b32 %1 offset:4352\n\tds_write_addtid_b32 %1 offset:4608\n\tds_write_addtid_b32 %1 offset:4864\n\t"
+                         "ds_write_addtid_b32 %1 offset:5120\n\tds_write_addtid_b32 %1 offset:5376\n\tds_write_addtid_b32 %1 offset:5632\n\tds_write_addtid_b32 %1 offset:5888\n\t"
+                         "ds_write_addtid_b32 %1 offset:6144\n\tds_write_addtid_b32 %1 offset:6400\n\tds_write_addtid_b32 %1 offset:6656\n\tds_write_addtid_b32 %1 offset:6912\n\t"
+                         "ds_write_addtid_b32 %1 offset:7168\n\tds_write_addtid_b32 %1 offset:7424\n\tds_write_addtid_b32 %1 offset:7680\n\tds_write_addtid_b32 %1 offset:7936\n\t"
+                         "ds_write_addtid_b32 %1 offset:8192\n\tds_write_addtid_b32 %1 offset:8448\n\tds_write_addtid_b32 %1 offset:8704\n\tds_write_addtid_b32 %1 offset:8960\n\t"
+                         "ds_write_addtid_b32 %1 offset:9216\n\tds_write_addtid_b32 %1 offset:9472\n\tds_write_addtid_b32 %1 offset:9728\n\tds_write_addtid_b32 %1 offset:9984"
+                         :: "s"(hist_lds), "v"(0u) : "memory");
         if (SPEC && lane < 8) corr[lane] = 0u;
     }
     __syncthreads();

@@ -570,7 +570,12 @@ int run_describe_planes(sift_hip_ctx *c, const sift_grad *d_grad, int nframes, c
     HIP_TRY(hipMemsetAsync(c->d_gate, 0, 4, s));
     // a caller's plane whose width is not a multiple of 4 is swept in its own format (its rows are not
     // 16-byte aligned, which the conversion kernel reads them by)
-    if (c->Wl != c->W) return run_describe<sift::GRAD_FULL32, MODE>(c, d_grad, nframes, d_kps, ori_in, ori_out, d_desc, s);
+    if (c->Wl != c->W) {
+        const size_t n = (size_t)nframes * (size_t)c->Wl * (size_t)c->H;   // the magnitude check k_grad_pairs would have made
+        hipLaunchKernelGGL(sift::k_grad_check, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, (const uint32_t *)d_grad, c->d_gate, n);
+        HIP_TRY(hipGetLastError());
+        return run_describe<sift::GRAD_FULL32, MODE>(c, d_grad, nframes, d_kps, ori_in, ori_out, d_desc, s);
+    }
     const dim3 grid((c->W / 4 + 255) / 256, (c->H + 3) / 4, nframes);
     hipLaunchKernelGGL(sift::k_grad_pairs, grid, dim3(256), 0, s, (const uint4 *)d_grad, c->d_gradp, c->d_gate, c->W, c->H);
     HIP_TRY(hipGetLastError());
@@ -1330,13 +1335,21 @@ namespace {
 constexpr int STATIC_MAX_DEVICES = 64;
 constexpr size_t STATIC_TABLE_BYTES = 256u << 10;     // front of the array: window + quad tables of the current width
 
+constexpr int STATIC_TABLE_SLOTS = 2;                 // widths whose tables stay in the array (a caller that alternates two sizes rebuilds nothing)
+struct StaticTables {
+    int width = 0;                        // frame width the tables of this slot were built for (0: empty)
+    long used = 0;                        // last call that used the slot
+    int ntab = 0, n2 = 0, n2pad = 0, qa = 0, qu2 = 0, qu = 0, qb = 0;
+    size_t qoff = 0;                      // byte offset of the quad table inside the slot
+};
 struct StaticState {
+    std::mutex mu;                        // calls on one device are serialised on the host; other devices do not wait
     unsigned char *base = nullptr;        // this device's address of `scratch` (hipGetSymbolAddress)
-    int table_width = 0;                  // frame width the tables in the array were built for
+    StaticTables tables[STATIC_TABLE_SLOTS];
+    long ncalls = 0;
     sift_hip_ctx ctx;                     // views into the array; owns nothing
 };
 StaticState g_static[STATIC_MAX_DEVICES];
-std::mutex g_static_mu;
 
 // the buffers of a call, carved out of the array behind the tables (256-byte aligned)
 struct StaticLayout {
@@ -1384,10 +1397,10 @@ int sift_hip_detect_and_compute_static(int device, const uint8_t *d_imgs, int nf
                  "(use a context: sift_hip_create)", nframes, width, height, L.end, (size_t)SIFT_HIP_STATIC_SCRATCH_BYTES);
         return fail(SIFT_HIP_EINVAL, buf);
     }
-    std::lock_guard<std::mutex> lock(g_static_mu);
+    StaticState &st = g_static[device];
+    std::lock_guard<std::mutex> lock(st.mu);
     DevGuard g(device);
     hipStream_t s = (hipStream_t)stream;
-    StaticState &st = g_static[device];
     if (!st.base) {
         // once per device, with that device current: its own address of the array
         int ndev = 0;
@@ -1406,27 +1419,41 @@ int sift_hip_detect_and_compute_static(int device, const uint8_t *d_imgs, int nf
         st.ctx.graph_max_frames = 0;
     }
     sift_hip_ctx *c = &st.ctx;
-    if (st.table_width != width) {
-        // set-up for a new frame width (first call, or the width changed): the descriptor tables hold
-        // plane offsets, so they are rebuilt on the host and copied to the front of the array.  The
-        // copy is ordered on `stream` after whatever earlier call still reads the old tables, and the
-        // host waits for it (the vectors go away); this step cannot run under stream capture.
+    st.ncalls++;
+    StaticTables *tb = nullptr;
+    for (StaticTables &t : st.tables) if (t.width == width) tb = &t;
+    if (!tb) {
+        // set-up for a frame width whose tables are not in the array (first call, or a third width): the descriptor
+        // tables hold plane offsets, so they are built on the host and copied into the slot used least recently.
+        // The copy is ordered on `stream` after whatever earlier call still reads that slot, and the host waits for
+        // it (the vectors go away); this step cannot run under stream capture.  Two widths stay resident, so a caller
+        // that alternates two frame sizes rebuilds nothing.
         const WindowTable wt = build_window_table(width, kGeometry[0]);
         const QuadTable qt = build_quad_table(width, kGeometry[0]);
         if (wt.e.empty()) return fail(SIFT_HIP_EINVAL, "circle tables overlap three-fold");
         if (2L * std::max(wt.kmax, qt.kmax) * sift::DESC_MAX_MAG_PACKED >= 65536)
             return fail(SIFT_HIP_EINVAL, "descriptor window too large for 16-bit lane bins");
         const size_t tab_bytes = wt.e.size() * sizeof(uint2), qoff = (tab_bytes + 255) & ~(size_t)255;
-        if (qoff + qt.bytes.size() > STATIC_TABLE_BYTES) return fail(SIFT_HIP_EINVAL, "descriptor tables exceed their share of the static array");
-        st.table_width = 0;
-        HIP_TRY(hipMemcpyAsync(st.base, wt.e.data(), tab_bytes, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(st.base + qoff, qt.bytes.data(), qt.bytes.size(), hipMemcpyHostToDevice, s));
+        if (qoff + qt.bytes.size() > STATIC_TABLE_BYTES / STATIC_TABLE_SLOTS) return fail(SIFT_HIP_EINVAL, "descriptor tables exceed their share of the static array");
+        tb = &st.tables[0];
+        for (StaticTables &t : st.tables) if (t.used < tb->used) tb = &t;
+        unsigned char *slot = st.base + (size_t)(tb - st.tables) * (STATIC_TABLE_BYTES / STATIC_TABLE_SLOTS);
+        tb->width = 0;
+        HIP_TRY(hipMemcpyAsync(slot, wt.e.data(), tab_bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(slot + qoff, qt.bytes.data(), qt.bytes.size(), hipMemcpyHostToDevice, s));
         HIP_TRY(hipStreamSynchronize(s));
-        c->d_tab = (uint2 *)st.base;
-        c->d_qtab = (uint32_t *)(st.base + qoff);
-        c->ntab = (int)wt.e.size(); c->n2 = wt.n2; c->n2pad = wt.n2pad;
-        c->qa = qt.qa; c->qu2 = qt.qu2; c->qu = qt.qu; c->qb = qt.qb;
-        st.table_width = width;
+        tb->ntab = (int)wt.e.size(); tb->n2 = wt.n2; tb->n2pad = wt.n2pad;
+        tb->qa = qt.qa; tb->qu2 = qt.qu2; tb->qu = qt.qu; tb->qb = qt.qb;
+        tb->qoff = qoff;
+        tb->width = width;
+    }
+    tb->used = st.ncalls;
+    {
+        unsigned char *slot = st.base + (size_t)(tb - st.tables) * (STATIC_TABLE_BYTES / STATIC_TABLE_SLOTS);
+        c->d_tab = (uint2 *)slot;
+        c->d_qtab = (uint32_t *)(slot + tb->qoff);
+        c->ntab = tb->ntab; c->n2 = tb->n2; c->n2pad = tb->n2pad;
+        c->qa = tb->qa; c->qu2 = tb->qu2; c->qu = tb->qu; c->qb = tb->qb;
     }
     c->W = width; c->Wl = width; c->H = height; c->S = (width + 63) / 64;
     c->npix = (size_t)width * height;

@@ -63,3 +63,20 @@ def test_match_against_the_oracle(sift, orc):
             assert (got[p] == orc.match(q[p], t[p])).all(), p
         with pytest.raises(sift.SiftHipError):
             ctx.match(np.zeros((40000, 72), np.uint32), t[0])
+
+
+@pytest.mark.gpu
+def test_match_distance_is_32_bits_wide(sift):
+    """DMatch_t::distance is an ap_uint<32> (SIFTParameters.hpp:124).  include/sift_hip.h supports rows whose
+    distances stay below 2^32 (what compute_descriptor produces cannot come near); beyond that the sum wraps modulo
+    2^32 like the field would.  This pins both sides of the documented limit, so that a later change cannot move it
+    unnoticed."""
+    with sift.SiftContext(64, 64) as ctx:
+        q = np.zeros((2, 72), np.uint32)
+        t = np.zeros((1, 72), np.uint32)
+        q[0, 0] = q[0, 1] = 0x7FFFFFFF                                # distance 0xfffffffe to the zero row: the largest exact case
+        m = ctx.match(q, t)
+        assert int(m["distance"][0]) == 0xFFFFFFFE and m["trainIdx"][0] == 0
+        q[0, 2] = 2                                                   # true distance 2^32: reads as 0 (wrapped), documented as unsupported
+        m = ctx.match(q, t)
+        assert int(m["distance"][0]) == 0 and m["trainIdx"][0] == 0

@@ -209,6 +209,24 @@ def test_caller_supplied_gradient_planes(sift, orc):
             assert e.value.code == -1 and "32767" in str(e.value)
         grad["ang"][100, 100] = 0                                      # not counted: the plane is fine
         assert (ctx.compute_main_orientation(grad, kps) == orc.main_orientation(grad, kps)).all()
+    # the same refusal for a width that is not a multiple of 4 (such planes are swept in their own format)
+    W3 = 323
+    kp3 = kps.copy()
+    kp3["x"][:n] = np.minimum(kp3["x"][:n], W3 - 1)
+    with sift.SiftContext(W3, H) as ctx3:
+        grad = np.zeros((H, W3), sift.GRAD_DTYPE)
+        grad["ang"] = rng.integers(0, 9, (H, W3))
+        grad["mag"] = rng.integers(0, 300, (H, W3))
+        ro3 = orc.main_orientation(grad, kp3)
+        assert (ctx3.compute_main_orientation(grad, kp3) == ro3).all()
+        grad["mag"][100, 100], grad["ang"][100, 100] = 40000, 3
+        for call in (lambda: ctx3.compute_main_orientation(grad, kp3), lambda: ctx3.compute_descriptor(grad, kp3, ro3)):
+            with pytest.raises(sift.SiftHipError) as e:
+                call()
+            assert e.value.code == -1 and "32767" in str(e.value)
+        grad["ang"][100, 100] = 9                                      # not counted
+        assert (ctx3.compute_main_orientation(grad, kp3) == orc.main_orientation(grad, kp3)).all()
+    with sift.SiftContext(W, H) as ctx:
         # worst case for the 16-bit bin halves of the fast kernel: every pixel 360, one direction
         grad = np.zeros((H, W), sift.GRAD_DTYPE)
         grad["ang"] = 2
@@ -553,32 +571,36 @@ def _oracle_frames(orc, imgs, th=15):
 def test_bench_shape_against_the_oracle(sift, orc):
     """cfg 4 at full size, the shape bench.py runs: 1920x1080 frames, more than 33 of them in one
     sift_hip_detect_and_compute_dev call, ~9,500 keypoints each -- so the grouped-slot descriptor
-    kernel with one band of keypoints per XCD (k_describe<..., LOOP = true, 5, 9, 2>) and the
-    long-strip blur kernel (k_blur<false>) run as they do in the bench.  Every frame's keypoint array,
-    valid descriptors, zero padding and total against the oracle (HW_SIFT.cpp:29-41 per frame)."""
+    kernel with one band of keypoints per XCD (k_describe<..., LOOP = true, 5, 4, 1, 2>), the matrix-core
+    blur (k_blur_mfma, strips picked for the batch) and the 12-row strips of k_detect run as they do in the
+    bench.  Every frame's keypoint array, valid descriptors, zero padding and total against the oracle
+    (HW_SIFT.cpp:29-41 per frame).  A second pass of 12 frames runs the same shape with the blurs on the vector
+    ALUs (k_blur<false>, long strips): the fallback for frames beyond 2^30 pixels and the comparison knob."""
     import torch
     W, H, B, K = 1920, 1080, 36, 10000
     imgs = np.stack([orc.synth_frame(1 + s, W, H) for s in range(B)])
     ref = _oracle_frames(orc, imgs)
     with sift.SiftContext(W, H, max_batch=B) as ctx:
         d_img = torch.from_numpy(imgs).cuda()
-        d_kps = torch.full((B, K, 2), -1, dtype=torch.int32, device="cuda")
-        d_desc = torch.full((B, K, 72), -1, dtype=torch.int32, device="cuda")
-        d_tot = torch.full((B,), -1, dtype=torch.int32, device="cuda")
-        ctx.detect_and_compute_dev(d_img, B, d_kps, d_desc, d_tot)
-        ctx.sync()
-        kps = d_kps.cpu().numpy().view(sift.KP_DTYPE).reshape(B, K)
-        desc = d_desc.cpu().numpy().view(np.uint32)
-        tot = d_tot.cpu().numpy()
-    nsum = 0
-    for b in range(B):
-        rk, rd, total = ref[b]
-        n = nvalid(rk)
-        nsum += n
-        assert (kps[b] == rk).all(), "keypoints of frame %d" % b
-        assert (desc[b, :n] == rd[:n]).all(), "descriptors of frame %d" % b
-        assert not desc[b, n:].any() and int(tot[b]) == total, b
-    assert nsum > 9000 * B                                          # dense frames, as in the bench
+        for mfma, nb in ((True, B), (False, 12)):
+            ctx.set_blur_mfma(mfma)
+            d_kps = torch.full((nb, K, 2), -1, dtype=torch.int32, device="cuda")
+            d_desc = torch.full((nb, K, 72), -1, dtype=torch.int32, device="cuda")
+            d_tot = torch.full((nb,), -1, dtype=torch.int32, device="cuda")
+            ctx.detect_and_compute_dev(d_img, nb, d_kps, d_desc, d_tot)
+            ctx.sync()
+            kps = d_kps.cpu().numpy().view(sift.KP_DTYPE).reshape(nb, K)
+            desc = d_desc.cpu().numpy().view(np.uint32)
+            tot = d_tot.cpu().numpy()
+            nsum = 0
+            for b in range(nb):
+                rk, rd, total = ref[b]
+                n = nvalid(rk)
+                nsum += n
+                assert (kps[b] == rk).all(), "keypoints of frame %d (mfma %r)" % (b, mfma)
+                assert (desc[b, :n] == rd[:n]).all(), "descriptors of frame %d (mfma %r)" % (b, mfma)
+                assert not desc[b, n:].any() and int(tot[b]) == total, (b, mfma)
+            assert nsum > 9000 * nb                                     # dense frames, as in the bench
 
 
 def test_detect_queue_drains_in_mid_strip(sift, orc):

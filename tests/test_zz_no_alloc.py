@@ -71,6 +71,39 @@ def test_static_entry_point_matches_the_context_entry_point(sift, orc):
         assert int(d_tot[b].item()) == total
 
 
+def test_static_entry_point_alternating_sizes_under_capture(sift, orc):
+    """The tables of the two most recently used widths stay in the array: a caller that alternates two frame sizes
+    rebuilds nothing, so those calls can be recorded into a HIP graph (a call that had to allocate, copy tables from the
+    host or synchronise would fail the capture) -- and the library's own creation counters stay where they were."""
+    import torch
+    from sift_amd.hw_sift import created_counts
+    a = np.stack([orc.synth_frame(31, 640, 480)])
+    b = np.stack([orc.synth_frame(32, 324, 201)])
+    want = {id(x): _context_call(sift, torch, x) for x in (a, b)}
+    for imgs in (a, b):                                                # both widths' tables become resident
+        _static_call(sift, torch, imgs)
+    before = created_counts()
+    lib = sift.load_library()
+    st = torch.cuda.Stream()
+    for imgs in (a, b, a, b):
+        B, H, W = imgs.shape
+        d_img = torch.from_numpy(imgs).cuda()
+        d_kps = torch.full((B, K, 2), -1, dtype=torch.int32, device="cuda")
+        d_desc = torch.full((B, K, 72), -1, dtype=torch.int32, device="cuda")
+        d_tot = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            sift.capi.check(lib.sift_hip_detect_and_compute_static(0, C.c_void_p(d_img.data_ptr()), B, W, H, C.c_void_p(d_kps.data_ptr()),
+                                                                   C.c_void_p(d_desc.data_ptr()), C.c_void_p(d_tot.data_ptr()), 15,
+                                                                   C.c_void_p(st.cuda_stream)))
+        g.replay()
+        torch.cuda.synchronize()
+        for got, w, what in zip((d_kps, d_desc, d_tot), want[id(imgs)], ("keypoints", "descriptors", "totals")):
+            assert torch.equal(got, w), "%s differ at %r" % (what, imgs.shape)
+    assert created_counts() == before
+
+
 def test_static_entry_point_rejects_what_does_not_fit(sift, orc):
     import torch
     two = np.stack([orc.synth_frame(1, 1920, 1080)] * 2)
