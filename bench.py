@@ -378,9 +378,10 @@ def end_to_end(sift_amd, dev, W, H, th, expected, frames_per_call=128, calls=8, 
                                     "p95": float(np.percentile(ms, 95))}}
 
         out = {"what": "pinned host frames in, pinned host results out (H2D 2.07 MB per frame), %dx%d, max_batch %d" % (W, H, max_batch)}
-        out["sift_hip_batch"] = timed(lambda: lib.sift_hip_batch(hs, 1, ps, n, C.c_void_p(p_kps), C.c_void_p(p_desc), th))
-        out["sift_hip_batch_top"] = timed(lambda: lib.sift_hip_batch_top(hs, 1, ps, n, NF, C.c_void_p(p_fk), C.c_void_p(p_fi),
-                                                                          C.c_void_p(p_fd), C.c_void_p(p_nv), th))
+        call_all = lambda: lib.sift_hip_batch(hs, 1, ps, n, C.c_void_p(p_kps), C.c_void_p(p_desc), th)
+        call_top = lambda: lib.sift_hip_batch_top(hs, 1, ps, n, NF, C.c_void_p(p_fk), C.c_void_p(p_fi), C.c_void_p(p_fd), C.c_void_p(p_nv), th)
+        out["sift_hip_batch"] = timed(call_all)
+        out["sift_hip_batch_top"] = timed(call_top)
         # the host-side results of the last sift_hip_batch call against the fixture
         if expected is not None:
             from sift_amd.checksum import words_checksum_np
@@ -389,6 +390,26 @@ def end_to_end(sift_amd, dev, W, H, th, expected, frames_per_call=128, calls=8, 
             if bad:
                 raise SystemExit("wrong result (sift_hip_batch, host buffers): seeds %r differ from the oracle" % bad)
             out["checked_frames"] = len(seeds[:16])
+        # the sparse regime (configs[0]: the reference's test image, 218 of 10,000 slots filled): every slot and descriptor
+        # row still travels back in sift_hip_batch (the contract: all 10,000 x 72 words written), only the 1000 strongest
+        # in sift_hip_batch_top -- whose rate is what a valid-rows-only copy could reach at most
+        if (W, H) == (1920, 1080):
+            from PIL import Image
+            g = os.path.join(ROOT, "tests", "golden")
+            im0 = np.asarray(Image.open(os.path.join(g, "im0_gray_1920x1080.png")), dtype=np.uint8)
+            for i in range(n):
+                imgs[i] = im0
+            sp = {"workload": "%d copies of the reference test image im0 (218 keypoints per frame)" % n,
+                  "sift_hip_batch": timed(call_all), "sift_hip_batch_top": timed(call_top)}
+            if th == 15:
+                z = np.load(os.path.join(g, "im0_expected.npz"))
+                nk = len(z["kps"])
+                k0 = kps[n - 1].view(sift_amd.KP_DTYPE).reshape(K)
+                d0 = desc[n - 1].reshape(K, 72)
+                if not ((k0[:nk] == z["kps"]).all() and (d0[:nk] == z["desc"]).all() and not d0[nk:].any() and int(nv[n - 1]) == nk):
+                    raise SystemExit("wrong result (sift_hip_batch on im0, host buffers)")
+                sp["checked_frames"] = 1
+            out["sparse"] = sp
         ctx.close()
         return out
     finally:

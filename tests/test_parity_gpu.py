@@ -288,6 +288,14 @@ def test_host_batch_call(sift, orc):
                 rk, rd, _ = ref[f]
                 m = nvalid(rk)
                 assert (kps[f] == rk).all() and (desc[f, :m] == rd[:m]).all() and not desc[f, m:].any(), (len(ctxs), n, f)
+        # a batch that mixes empty, sparse and dense frames (th = 1 fills the slots)
+        mixed = [np.zeros((H, W), np.uint8), imgs[0], imgs[1], np.zeros((H, W), np.uint8), imgs[2]]
+        for th in (15, 1):
+            kps, desc = batch([c, a], mixed, th)
+            for f, im in enumerate(mixed):
+                rk, rd, _ = orc.detect_and_compute(im, th)
+                m = nvalid(rk)
+                assert (kps[f] == rk).all() and (desc[f, :m] == rd[:m]).all() and not desc[f, m:].any(), (th, f)
         # frames that are neighbours in host memory (one array): the run-length upload path
         block = np.stack(imgs)
         kps, desc = batch([a, b, c], list(block))

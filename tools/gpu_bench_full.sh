@@ -13,5 +13,6 @@ for o in d.get("other_configs", []):
     print(o["workload"][:60], "fps %.0f" % o["value"], o.get("kernel_ms_per_step"), o.get("cpu_baseline", {}).get("value"), o["checked_frames"])
 e=d.get("end_to_end") or {}
 for k,v in e.items():
-    if isinstance(v, dict): print(k, "fps %.0f" % v["value"], v["ms_per_call"])
+    if isinstance(v, dict) and "value" in v: print(k, "fps %.0f" % v["value"], v["ms_per_call"])
+    if k == "sparse": print("sparse:", {kk: round(vv["value"]) for kk, vv in v.items() if isinstance(vv, dict)})
 PY
