@@ -232,29 +232,22 @@ constexpr int DETECT_QUEUE = DETECT_QUEUE_ENTRIES;
 static_assert(DETECT_QUEUE >= 2 * 256, "a row must fit after a drain");
 
 
-// One wave's share of k_detect.  PAIR = false: 64 groups of one strip.  PAIR = true (the last span of a row whose
-// remainder is at most 32 groups, 1920 pixels = 7.5 waves): lanes 0-31 take the span's groups in strip 2 * blockIdx.y,
-// lanes 32-63 the same groups in the strip below it, so the half-filled wave does two strips' work in one pass
-// (rows is then a multiple of 4 and at most DETECT_ROWS / 2: the host decides, run_detect).  In that mode the row
-// number, the strip's limits and everything derived from them are per lane; the wave as a whole covers the rows
-// [ys, ye) of both strips, which is what the candidate map and the final stores index.
-template <bool FULLGRAD, bool PAIR>
-__device__ __forceinline__ void detect_wave(uint32_t (&queue)[3][DETECT_QUEUE], u64 (&cmap)[DETECT_ROWS * 4],
-                                            const uint4 *__restrict__ pyr,
-                                            u64 *__restrict__ candmask, uint32_t *__restrict__ keyplane,
-                                            uint32_t *__restrict__ rowcount,
-                                            uint16_t *__restrict__ gradp, uint32_t *__restrict__ gradfull,
-                                            int W, int H, int S, int contrastTh, int rows, int qcap, int Wl)
+// grid: x = ceil(W/256) spans, y = strips of `rows` <= DETECT_ROWS, z = frames; block = 64 (one wave)
+template <bool FULLGRAD>
+__global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
+                                               u64 *__restrict__ candmask, uint32_t *__restrict__ keyplane,
+                                               uint32_t *__restrict__ rowcount,
+                                               uint16_t *__restrict__ gradp, uint32_t *__restrict__ gradfull,
+                                               int W, int H, int S, int contrastTh, int rows, int qcap, int Wl)
 {
+    __shared__ uint32_t queue[3][DETECT_QUEUE];       // [0]: y << 16 | x, [1]: fxx | fyy << 16, [2]: fxy | D2 << 16 (binary16)
+    __shared__ u64 cmap[DETECT_ROWS * 4];             // candidate bits of the strip: row-major, 4 words per row
+
     const int lane = threadIdx.x;
     const int W4 = W >> 2;
-    const int half = PAIR ? lane >> 5 : 0;
-    const int g = blockIdx.x * 64 + (PAIR ? lane & 31 : lane);   // 4-pixel group of this lane
-    const int ys = (PAIR ? 2 : 1) * blockIdx.y * rows;           // the wave's rows [ys, ye): wave-uniform
-    if (PAIR && ys >= H) return;                                 // (half as many waves as strips in this span)
-    const int ye = min(H, ys + (PAIR ? 2 : 1) * rows);
-    const int yea = min(H, ys + rows);                           // end of the first strip: the loop's limit
-    const int ysl = ys + half * rows, yel = max(ysl, min(H, ysl + rows));   // the lane's strip (empty below the image)
+    const int g = blockIdx.x * 64 + lane;             // 4-pixel group of this lane
+    const int ys = blockIdx.y * rows;
+    const int ye = min(H, ys + rows);
     const int frame = blockIdx.z;
     const size_t fpix = (size_t)frame * (size_t)W * (size_t)H;
     const uint4 *__restrict__ fp = pyr + (fpix >> 2);
@@ -263,9 +256,8 @@ __device__ __forceinline__ void detect_wave(uint32_t (&queue)[3][DETECT_QUEUE], 
     cmap[lane + 64] = 0ull;
     __syncthreads();
     const bool colvalid = g < W4;
-    // halo column: the pixel left of the wave (half wave) for its first lane, right of it for its last
-    const bool endl = PAIR ? (lane & 31) == 0 : lane == 0, endr = PAIR ? (lane & 31) == 31 : lane == 63;
-    const int gh = endl ? g - 1 : g + 1;
+    // halo column: the pixel left of the wave for lane 0, right of it for lane 63
+    const int gh = lane == 0 ? g - 1 : g + 1;
 
     // A row is read through a buffer descriptor of exactly its W4 groups (none for rows outside the
     // image): lanes beyond the row, the halo lanes at the frame's left and right edge (offset -16
@@ -274,41 +266,23 @@ __device__ __forceinline__ void detect_wave(uint32_t (&queue)[3][DETECT_QUEUE], 
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     // only lanes 0 and 63 use their halo group: the others ask for an offset beyond the row, which the bounds check
     // answers with zeros without a trip to the cache
-    // (PAIR: the two halves read different rows, so the descriptor spans the frame -- the host checks that it fits
-    // 32 bits -- and the lanes that the row-sized descriptor would have refused ask for an offset outside it)
-    constexpr uint32_t OUTSIDE = 0xfffffff0u;
-    const uint32_t goff = (!PAIR || colvalid) ? (uint32_t)g * 16u : OUTSIDE;
-    const uint32_t hoff = ((endl || endr) && (!PAIR || (gh >= 0 && gh < W4))) ? (uint32_t)gh * 16u : OUTSIDE;
-    const __amdgpu_buffer_rsrc_t rs_frame = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint4 *>(fp), 0, PAIR ? (int)((uint32_t)W4 * 16u * (uint32_t)H) : 0, 0x00020000);
-    auto load_row = [&](int r, uint4 &Q, uint4 &Qh) {                            // r: the row for the first strip's lanes
+    const uint32_t goff = (uint32_t)g * 16u, hoff = (lane == 0 || lane == 63) ? (uint32_t)gh * 16u : 0xfffffff0u;
+    auto load_row = [&](int r, uint4 &Q, uint4 &Qh) {
 #ifdef DET_EXP_HOTLOAD
         r = ys;                                                                  // timing only: every request reads the strip's first row
 #endif
-        u32x4 a, b;
-        if constexpr (PAIR) {
-            const int rl = r + half * rows;
-            const bool in = (unsigned)rl < (unsigned)H;
-            const uint32_t ro = __umul24((uint32_t)rl, (uint32_t)W4 * 16u);      // both below 2^24, the product below 2^32
-            a = __builtin_amdgcn_raw_buffer_load_b128(rs_frame, (int)(in && colvalid ? ro + goff : OUTSIDE), 0, 0);
-            b = __builtin_amdgcn_raw_buffer_load_b128(rs_frame, (int)(in && hoff != OUTSIDE ? ro + hoff : OUTSIDE), 0, 0);
-        } else {
-            const bool in = r >= 0 && r < H;                                     // wave-uniform
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<uint4 *>(fp + (size_t)(in ? r : 0) * W4), 0, in ? W4 * 16 : 0, 0x00020000);
-            a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)goff, 0, 0);
+        const bool in = r >= 0 && r < H;                                         // wave-uniform
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint4 *>(fp + (size_t)(in ? r : 0) * W4), 0, in ? W4 * 16 : 0, 0x00020000);
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)goff, 0, 0);
 #ifdef DET_EXP_NOHALO
-            b = a;                                                               // timing only
+        const u32x4 b = a;                                                       // timing only
 #else
-            b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)hoff, 0, 0);
+        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)hoff, 0, 0);
 #endif
-        }
         Q = make_uint4(a.x, a.y, a.z, a.w);
         Qh = make_uint4(b.x, b.y, b.z, b.w);
     };
-    // neighbouring lane's value, the halo's at the ends of the wave (of each half wave)
-    auto fl = [&](int old, int v) { const int d = from_left(old, v); return PAIR && lane == 32 ? old : d; };
-    auto fr = [&](int old, int v) { const int d = from_right(old, v); return PAIR && lane == 31 ? old : d; };
 
     // Per pair of columns and row: e = max(D1, D3), f = min(D1, D3), m = max(D1, D2, D3), n = min(D1, D2, D3)
     // and b = D2, as packed halves (even pair, odd pair).  Three rows are held (y-1, y, y+1) in three slots whose
@@ -320,7 +294,7 @@ __device__ __forceinline__ void detect_wave(uint32_t (&queue)[3][DETECT_QUEUE], 
     uint32_t g2[3], hg2[3];                           // G2 dwords of the lane's group and of the halo group
     // the halo pair: lane 0 needs pixel 3 of the group to its left (the odd pair's high half), lane 63 pixel 0 of
     // the group to its right (the even pair's low half)
-    const uint32_t hsel = endl ? H2_SEL_ODD : H2_SEL_EVEN;
+    const uint32_t hsel = lane == 0 ? H2_SEL_ODD : H2_SEL_EVEN;
     // row r into slot k
     auto push = [&](const uint4 &Q, const uint4 &Qh, int k) {
         const uint32_t sel[2] = {H2_SEL_EVEN, H2_SEL_ODD};
@@ -344,8 +318,8 @@ __device__ __forceinline__ void detect_wave(uint32_t (&queue)[3][DETECT_QUEUE], 
             hb[k] = d2;
         }
         // (DPP shifts: every lane is active here)
-        bl[k] = __builtin_amdgcn_alignbit(sb[k][1], (uint32_t)fl((int)hb[k], (int)sb[k][1]), 16);     // columns -1, 1
-        br[k] = __builtin_amdgcn_alignbit((uint32_t)fr((int)hb[k], (int)sb[k][0]), sb[k][0], 16);    // columns 2, 4
+        bl[k] = __builtin_amdgcn_alignbit(sb[k][1], (uint32_t)from_left((int)hb[k], (int)sb[k][1]), 16);     // columns -1, 1
+        br[k] = __builtin_amdgcn_alignbit((uint32_t)from_right((int)hb[k], (int)sb[k][0]), sb[k][0], 16);    // columns 2, 4
         hd[k][0] = h2_sub(bl[k], sb[k][1]);
         hd[k][1] = h2_sub(sb[k][0], br[k]);
         g2[k] = Q.z;
@@ -391,13 +365,10 @@ __device__ __forceinline__ void detect_wave(uint32_t (&queue)[3][DETECT_QUEUE], 
     const h2 thh = h2_sub(thbits | thbits << 16, 0x64006400u);                                          // ... - 1024, both halves
     const u64 colmask = __ballot(colvalid);
     // one image row; A, B, C = slots of rows y-1, y, y+1 (C is overwritten with row y+1)
-    auto row = [&](int yu, auto ka, auto kb, auto kc) {                     // yu: the row of the first strip's lanes
+    auto row = [&](int y, auto ka, auto kb, auto kc) {
         constexpr int A = decltype(ka)::value, B = decltype(kb)::value, C = decltype(kc)::value;
-        const int y = yu + half * rows;                                  // the lane's row
-        const bool rowvalid = !PAIR || y < yel;                          // (the lower strip may be short or absent)
-        const u64 rowmask = PAIR ? __ballot(colvalid && rowvalid) : colmask;
         Q = Qn; Qh = Qhn;                                                // row y+1
-        load_row(yu + 2, Qn, Qhn);                                       // prefetch (a row past the strip is harmless; requesting rows
+        load_row(y + 2, Qn, Qhn);                                        // prefetch (a row past the strip is harmless; requesting rows
                                                                          // three iterations ahead was measured: 1.3 % slower)
         push(Q, Qh, C);
 
@@ -408,10 +379,10 @@ __device__ __forceinline__ void detect_wave(uint32_t (&queue)[3][DETECT_QUEUE], 
         const h2 XE = h2_max3(sm[A][0], sm[B][0], sm[C][0]), XO = h2_max3(sm[A][1], sm[B][1], sm[C][1]);
         const h2 NE = h2_min3(sn[A][0], sn[B][0], sn[C][0]), NO = h2_min3(sn[A][1], sn[B][1], sn[C][1]);
         const h2 hX = h2_max3(hm[A], hm[B], hm[C]), hN = h2_min3(hn[A], hn[B], hn[C]);
-        const h2 XlE = __builtin_amdgcn_alignbit(XO, (uint32_t)fl((int)hX, (int)XO), 16);    // columns -1, 1
-        const h2 NlE = __builtin_amdgcn_alignbit(NO, (uint32_t)fl((int)hN, (int)NO), 16);
-        const h2 XrO = __builtin_amdgcn_alignbit((uint32_t)fr((int)hX, (int)XE), XE, 16);   // columns 2, 4
-        const h2 NrO = __builtin_amdgcn_alignbit((uint32_t)fr((int)hN, (int)NE), NE, 16);
+        const h2 XlE = __builtin_amdgcn_alignbit(XO, (uint32_t)from_left((int)hX, (int)XO), 16);    // columns -1, 1
+        const h2 NlE = __builtin_amdgcn_alignbit(NO, (uint32_t)from_left((int)hN, (int)NO), 16);
+        const h2 XrO = __builtin_amdgcn_alignbit((uint32_t)from_right((int)hX, (int)XE), XE, 16);   // columns 2, 4
+        const h2 NrO = __builtin_amdgcn_alignbit((uint32_t)from_right((int)hN, (int)NE), NE, 16);
         const h2 mxE = h2_max3(XlE, h2_max3(se[B][0], sm[A][0], sm[C][0]), XO);
         const h2 mxO = h2_max3(XE, h2_max3(se[B][1], sm[A][1], sm[C][1]), XrO);
         const h2 mnE = h2_min3(NlE, h2_min3(sf[B][0], sn[A][0], sn[C][0]), NO);
@@ -420,10 +391,10 @@ __device__ __forceinline__ void detect_wave(uint32_t (&queue)[3][DETECT_QUEUE], 
         // masks straight from the comparisons (pixel p: even pair low, odd low, even high, odd high)
         const h2 cE = sb[B][0], cO = sb[B][1];
         const u64 pm[4] = {
-            (h2_gt<0>(cE, mxE) | h2_gt<0>(mnE, cE)) & h2_abs_ge<0>(cE, thh) & rowmask,
-            (h2_gt<0>(cO, mxO) | h2_gt<0>(mnO, cO)) & h2_abs_ge<0>(cO, thh) & rowmask,
-            (h2_gt<1>(cE, mxE) | h2_gt<1>(mnE, cE)) & h2_abs_ge<1>(cE, thh) & rowmask,
-            (h2_gt<1>(cO, mxO) | h2_gt<1>(mnO, cO)) & h2_abs_ge<1>(cO, thh) & rowmask,
+            (h2_gt<0>(cE, mxE) | h2_gt<0>(mnE, cE)) & h2_abs_ge<0>(cE, thh) & colmask,
+            (h2_gt<0>(cO, mxO) | h2_gt<0>(mnO, cO)) & h2_abs_ge<0>(cO, thh) & colmask,
+            (h2_gt<1>(cE, mxE) | h2_gt<1>(mnE, cE)) & h2_abs_ge<1>(cE, thh) & colmask,
+            (h2_gt<1>(cO, mxO) | h2_gt<1>(mnO, cO)) & h2_abs_ge<1>(cO, thh) & colmask,
         };
         if ((pm[0] | pm[1] | pm[2] | pm[3]) != 0ull) {
             // second differences of D2 at every pixel of the row (:318-322): fxx = L + R - 2c, fyy = U + Dn - 2c,
@@ -451,9 +422,9 @@ __device__ __forceinline__ void detect_wave(uint32_t (&queue)[3][DETECT_QUEUE], 
         // gradient of G2 at row y (:1189-1190): gx from the row itself, gy from rows y-1 and y+1
         // (the DPP shifts run with every lane active: a disabled source lane would leave `old`)
         const uint32_t g2b = g2[B];
-        const uint32_t lw = (uint32_t)fl((int)hg2[B], (int)g2b);              // G2 dword of the group to the left
-        const uint32_t rw = (uint32_t)fr((int)hg2[B], (int)g2b);
-        if (colvalid && rowvalid) {
+        const uint32_t lw = (uint32_t)from_left((int)hg2[B], (int)g2b);       // G2 dword of the group to the left
+        const uint32_t rw = (uint32_t)from_right((int)hg2[B], (int)g2b);
+        if (colvalid) {
             uint32_t gp[4], gf[4];
 #pragma unroll
             for (int p = 0; p < 4; p++) {
@@ -487,20 +458,20 @@ __device__ __forceinline__ void detect_wave(uint32_t (&queue)[3][DETECT_QUEUE], 
             o.y = gp[2] | gp[3];
             // the four rows of a group are 32 neighbouring bytes per quad: they are kept until the
             // group is complete and leave as one piece (a strip that starts or ends inside a group
-            // stores its rows one by one); y, ysl and yel are wave-uniform unless PAIR
+            // stores its rows one by one); y, ys and ye are wave-uniform
             uint16_t *const gq = gradp + gradp_frame_words(W, H) * (size_t)frame;
             const int yr = y & 3;
 #ifdef DET_EXP_NOGRADSTORE
-            if (yr == 3 && y - 3 >= ysl) {                               // timing only: the gradient words are computed, not stored
+            if (yr == 3 && y - 3 >= ys) {                                // timing only: the gradient words are computed, not stored
                 asm volatile("" :: "v"(gb0.x ^ gb0.y ^ gb1.x ^ gb1.y ^ gb2.x ^ gb2.y ^ o.x ^ o.y));
-            } else if (y - yr < ysl || (y | 3) >= yel) {
+            } else if (y - yr < ys || (y | 3) >= ye) {
                 asm volatile("" :: "v"(o.x ^ o.y));
 #else
-            if (yr == 3 && y - 3 >= ysl) {
+            if (yr == 3 && y - 3 >= ys) {
                 uint4 *dst = reinterpret_cast<uint4 *>(gq + gradp_quad_word(y - 3, g, W4));
                 dst[0] = make_uint4(gb0.x, gb0.y, gb1.x, gb1.y);
                 dst[1] = make_uint4(gb2.x, gb2.y, o.x, o.y);
-            } else if (y - yr < ysl || (y | 3) >= yel) {
+            } else if (y - yr < ys || (y | 3) >= ye) {
                 *reinterpret_cast<uint2 *>(gq + gradp_quad_word(y, g, W4)) = o;
 #endif
             } else if (yr == 0) {
@@ -517,10 +488,10 @@ __device__ __forceinline__ void detect_wave(uint32_t (&queue)[3][DETECT_QUEUE], 
         using K1 = std::integral_constant<int, 1>;
         using K2 = std::integral_constant<int, 2>;
         // (qcap is DETECT_QUEUE except in the test that forces drains, sift_hip_set_detect_queue)
-        for (int y = ys; y < yea; y += 3) {
+        for (int y = ys; y < ye; y += 3) {
             row(y, K0{}, K1{}, K2{});
-            if (y + 1 < yea) row(y + 1, K1{}, K2{}, K0{});
-            if (y + 2 < yea) row(y + 2, K2{}, K0{}, K1{});
+            if (y + 1 < ye) row(y + 1, K1{}, K2{}, K0{});
+            if (y + 2 < ye) row(y + 2, K2{}, K0{}, K1{});
         }
     }
 
@@ -532,23 +503,6 @@ __device__ __forceinline__ void detect_wave(uint32_t (&queue)[3][DETECT_QUEUE], 
         if (ys + row < ye && seg < S) candmask[(frow + ys + row) * S + seg] = cmap[wi];
     }
     if (blockIdx.x == 0 && lane < ye - ys) rowcount[frow + ys + lane] = 0u;
-}
-
-// grid: x = ceil(W/256) spans, y = strips of `rows` <= DETECT_ROWS, z = frames; block = 64 (one wave).
-// pair_span: the span whose waves take two strips each (detect_wave<.., true>), or -1.
-template <bool FULLGRAD>
-__global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
-                                               u64 *__restrict__ candmask, uint32_t *__restrict__ keyplane,
-                                               uint32_t *__restrict__ rowcount,
-                                               uint16_t *__restrict__ gradp, uint32_t *__restrict__ gradfull,
-                                               int W, int H, int S, int contrastTh, int rows, int qcap, int Wl, int pair_span)
-{
-    __shared__ uint32_t queue[3][DETECT_QUEUE];       // [0]: y << 16 | x, [1]: fxx | fyy << 16, [2]: fxy | D2 << 16 (binary16)
-    __shared__ u64 cmap[DETECT_ROWS * 4];             // candidate bits of the wave's rows: row-major, 4 words per row
-    if ((int)blockIdx.x == pair_span)
-        detect_wave<FULLGRAD, true>(queue, cmap, pyr, candmask, keyplane, rowcount, gradp, gradfull, W, H, S, contrastTh, rows, qcap, Wl);
-    else
-        detect_wave<FULLGRAD, false>(queue, cmap, pyr, candmask, keyplane, rowcount, gradp, gradfull, W, H, S, contrastTh, rows, qcap, Wl);
 }
 
 }  // namespace sift

@@ -491,22 +491,12 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
         }
         drows = std::max(4, std::min(drows, (int)sift::DETECT_ROWS));
         dim3 grid(spans, (H + drows - 1) / drows, nframes);
-        // A last span of at most 32 groups (1920 pixels: 7.5 waves per row) runs two strips per wave, one per half
-        // wave: measured with tools/detect_width.py, the half-filled wave costs what a full one does.  The mode needs
-        // whole 4-row gradient groups per strip, both strips in the wave's candidate map and a frame that one
-        // buffer descriptor spans.
-        const int rem = (W / 4) - 64 * (spans - 1);
-        int pair_span = -1;
-#ifndef DETECT_NO_PAIR
-        if (rem <= 32 && drows % 4 == 0 && 2 * drows <= (int)sift::DETECT_ROWS && (unsigned long long)c->npix * 4ull <= 0xfffffff0ull)
-            pair_span = spans - 1;
-#endif
         if (d_gradfull)
             hipLaunchKernelGGL(sift::k_detect<true>, grid, dim3(64), 0, s, c->d_pyr, c->d_cand, c->d_key,
-                               c->d_rowcount, c->d_gradp, d_gradfull, W, H, S, th, drows, c->detect_queue, c->Wl, pair_span);
+                               c->d_rowcount, c->d_gradp, d_gradfull, W, H, S, th, drows, c->detect_queue, c->Wl);
         else
             hipLaunchKernelGGL(sift::k_detect<false>, grid, dim3(64), 0, s, c->d_pyr, c->d_cand, c->d_key,
-                               c->d_rowcount, c->d_gradp, (uint32_t *)nullptr, W, H, S, th, drows, c->detect_queue, c->Wl, pair_span);
+                               c->d_rowcount, c->d_gradp, (uint32_t *)nullptr, W, H, S, th, drows, c->detect_queue, c->Wl);
     }
     {
         StageTimer t(c, ST_CULL, s);
