@@ -6,6 +6,7 @@ the shared library is missing; nothing here falls back to a CPU path.
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -64,6 +65,17 @@ def load_library():
         return _lib
     if not os.path.exists(_LIB):
         raise SiftHipError(-3, "libsift_hip.so not built (%s); run sift_amd.build_library()" % _LIB)
+    # A process that also uses PyTorch-ROCm must bring PyTorch's GPU runtime up first (INTEGRATION.md section 5:
+    # the wheel carries its own HIP runtime, and torch.cuda does not initialise once /opt/rocm's is up).  When
+    # torch is already imported that order is made here rather than left to the caller; torch is never imported
+    # for it, and a process without torch is not affected.
+    torch = sys.modules.get("torch")
+    if torch is not None and getattr(getattr(torch, "version", None), "hip", None):
+        try:
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:                                    # no usable GPU for torch: the library reports its own errors
+            pass
     lib = C.CDLL(_LIB)
     vp, i32 = C.c_void_p, C.c_int
     lib.sift_hip_last_error.restype = C.c_char_p

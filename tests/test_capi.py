@@ -91,3 +91,22 @@ def test_product_does_not_import_the_oracle():
                     if re.search(r"\boracle\b|sift_oracle|liborc|orc_", t):
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_loader_brings_torch_up_first():
+    """a process that imported torch without touching the GPU, then uses this library, then
+    torch.cuda -- the loader initialises torch's runtime first, so all three work (a fresh process: the order matters
+    once per process)."""
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import sift_amd as sift\n"
+        "with sift.SiftContext(256, 192) as ctx:\n"
+        "    kps, desc = ctx.sift_detect_and_compute(np.zeros((192, 256), np.uint8), 15)\n"
+        "assert not np.asarray(desc).any()\n"
+        "t = torch.arange(8, device='cuda:0')\n"
+        "assert int(t.sum().item()) == 28\n"
+        "print('ok')\n" % ROOT)
+    r = subprocess.run([os.environ.get("PYTHON", "python"), "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
