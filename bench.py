@@ -605,13 +605,14 @@ def main():
             def roof_blur_mfma():
                 """k_blur runs on the matrix cores: its bound is MFMA issue, not HBM.  `achieved` counts the
                 ALGORITHMIC integer operations (507 MAC = 1014 op per pixel); the banded products
-                issue 3840 MAC per pixel (60 MFMAs of 16x16x64 per 256 pixels and input row), which is what
+                issue 2304 MAC per pixel (36 MFMAs of 16x16x64 per 256 pixels and input row: an operand is two
+                input rows x 32 pixels, a result tile two output rows x 8 pixels), which is what
                 keeps the matrix cores busy (mfma_busy_frac, from the committed counter pass)."""
                 t = stage["k_blur"] * 1e-3
                 ach = 2.0 * 507.0 * W * H * B / t / 1e12
                 r = {"kernel": "k_blur", "bound": "mfma", "achieved": ach, "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s (i8)",
                      "frac": ach / I8_MFMA_PEAK_TOPS, "traffic": float(traffic["k_blur"]["hbm_bytes_per_launch"]) if traffic.get("k_blur") else None,
-                     "algorithmic_ops_per_launch": 2.0 * 507.0 * W * H * B, "issued_macs_per_pixel": 3840, "avg_launch_ms": stage["k_blur"],
+                     "algorithmic_ops_per_launch": 2.0 * 507.0 * W * H * B, "issued_macs_per_pixel": 36 * 16384 // 256, "avg_launch_ms": stage["k_blur"],
                      "hbm": roof("k_blur")}
                 if units.get("k_blur", {}).get("mfma_busy_frac") is not None:
                     r["mfma_busy_frac"] = units["k_blur"]["mfma_busy_frac"]
