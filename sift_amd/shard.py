@@ -63,14 +63,16 @@ def check_ranks(world_expected, world_seen, identities, shared_ok):
 class DistEnv:
     """One process per GPU, launched by torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*)."""
 
-    def __init__(self, backend=None, device=None):
+    def __init__(self, backend=None, device=None, force_group=False):
+        """force_group: build the process group even for one rank (the test that runs this class's collectives
+        through RCCL on a one-GPU box)"""
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.backend = backend
         self._dist = None
         self._device = None
-        if self.world > 1:
+        if self.world > 1 or force_group:
             import torch
             import torch.distributed as dist
             if backend is None:

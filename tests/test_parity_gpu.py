@@ -678,6 +678,36 @@ def test_bench_two_ranks_sharing_the_gpu(sift):
         assert d["ranks_seen"] == 2 and d["devices"] == [0, 0] and d["distinct_gpus"] == 1 and d["backend"] == "gloo"
 
 
+def test_rccl_collectives_of_the_launcher_on_one_rank():
+    """VERDICT r2 "the RCCL launch path has never run": the collectives bench.py's N > 1 branch uses (barrier, max,
+    sum, all-gather of the device identity) through the `nccl` backend = RCCL, on a process group of one rank on the
+    box's one GPU -- RCCL loads, initialises on the device and answers.  More ranks need a multi-GPU node."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from sift_amd.shard import DistEnv, check_ranks, device_identity, pick_device\n"
+        "dev = pick_device(0, torch.cuda.device_count())\n"
+        "env = DistEnv(backend=None, device=dev, force_group=True)\n"
+        "assert env.backend == 'nccl' and env.dist_world_size() == 1\n"
+        "env.barrier()\n"
+        "ids = env.gather_ints(device_identity(torch.cuda.get_device_properties(dev), dev))\n"
+        "check_ranks(1, env.dist_world_size(), ids, False)\n"
+        "assert env.max_over_ranks(1.5) == 1.5 and env.sum_over_ranks(41) == 41 and ids[0] > 0\n"
+        "env.close()\n"
+        "print('ok')\n" % root)
+    envv = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    envv.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=170, env=envv)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
 def test_cam1_geometry(sift, orc):
     """the reference's second set of descriptor tables (81 x 81 window, 29 x 29 circle mask,
     XStartCam1 / YStartCam1, MaskAll_81), which its code never reads; semantics = the Cam0 loops with those
