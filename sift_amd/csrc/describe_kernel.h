@@ -212,7 +212,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GFMT == 0 ? 
         continue;
     }
     const kp_t kp = kps[slot];
+#ifdef DESC_EXP_EMPTY
+    const int px = 0, py = kp.y;                      // timing only: every slot takes the padding path (load, two stores)
+#else
     const int px = kp.x, py = kp.y;
+#endif
     uint32_t *__restrict__ out = desc ? desc + slot * 72 : nullptr;
 
     if (!(px > 0 && py > 0)) {                       // :52 / :196 -- padding slot
@@ -292,7 +296,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GFMT == 0 ? 
         }
     };
     auto add = [&](uint32_t byteofs, uint32_t v) {
+#ifdef DESC_EXP_NOADDS
+        asm volatile("" :: "v"(byteofs), "v"(v));                       // timing only: address and value formed, no LDS instruction
+#else
         atomicAdd(reinterpret_cast<uint32_t *>(hbase + byteofs), v);
+#endif
     };
     auto accumulate = [&](auto two, uint32_t hi, uint32_t g) {
         if constexpr (PACK) {
@@ -360,7 +368,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GFMT == 0 ? 
         const uint32_t v = pair_v(odd, d);
         const uint32_t rl = pair_rl(odd, d);
         add(((cc & 15u) << 9) | rl, v);
+#ifdef DESC_EXP_ONEADD
+        if constexpr (false) {                                          // timing only: one add per pixel of a two-circle quad
+#else
         if constexpr (decltype(two)::value) {
+#endif
             add((((cc >> 4) & 15u) << 9) | rl, v);
             add((ovsel & 0x400u) | (rl | (9u << 9)), v);
         }
@@ -472,6 +484,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GFMT == 0 ? 
         uint32_t rec[ND];
 #pragma unroll
         for (int i = 0; i < ND / 4; i++) {
+#ifdef DESC_EXP_FEWER
+            if (i == ND / 4 - 1) { rec[4 * i] = rec[0] * 3u; rec[4 * i + 1] = rec[1] * 5u; rec[4 * i + 2] = rec[2] * 7u; rec[4 * i + 3] = rec[3] * 9u; continue; }   // timing only: three table loads
+#endif
             const uint4 v = *reinterpret_cast<const uint4 *>(tq + QuadRecord::at((uint32_t)lane, (uint32_t)i * 16u));
             rec[4 * i] = v.x; rec[4 * i + 1] = v.y; rec[4 * i + 2] = v.z; rec[4 * i + 3] = v.w;
         }
@@ -485,13 +500,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GFMT == 0 ? 
 #pragma unroll
         for (int u = 0; u < NB; u++) eb[u] = rec[R.offB / 4 + u];
 #pragma unroll
+#ifdef DESC_EXP_NOGATHER
+        // timing only: the quads' words are made up from the table entries, nothing is read from the plane
+        for (int u = 0; u < NA; u++) qa_[u] = make_uint2(ea[u].x * 0x9E3779B1u, ea[u].y * 0x85EBCA6Bu);
+#pragma unroll
+        for (int u = 0; u < NU2; u++) qu2_[u] = make_uint4(eu2[u] * 0x9E3779B1u, eu2[u] * 0x85EBCA6Bu, eu2[u] * 0xC2B2AE35u, eu2[u] * 0x27D4EB2Fu);
+#pragma unroll
+        for (int u = 0; u < NU; u++) qu_[u] = make_uint2(eu[u] * 0x9E3779B1u, eu[u] * 0x85EBCA6Bu);
+#pragma unroll
+        for (int u = 0; u < NB; u++) qb_[u] = make_uint2(eb[u] * 0x9E3779B1u, eb[u] * 0x85EBCA6Bu);
+#else
+#ifdef DESC_EXP_FEWER
+        // timing only: what a table with paired two-circle quads would cost -- two of the five A gathers made up
+        for (int u = 0; u < NA; u++) qa_[u] = u < 3 ? *reinterpret_cast<const uint2 *>(gq + (ea[u].x & 0xffffffu)) : make_uint2(ea[u].x * 0x9E3779B1u, ea[u].y * 0x85EBCA6Bu);
+#else
         for (int u = 0; u < NA; u++) qa_[u] = *reinterpret_cast<const uint2 *>(gq + (ea[u].x & 0xffffffu));
+#endif
 #pragma unroll
         for (int u = 0; u < NU2; u++) qu2_[u] = *reinterpret_cast<const uint4 *>(gq + u_offset(eu2[u]));
 #pragma unroll
         for (int u = 0; u < NU; u++) qu_[u] = *reinterpret_cast<const uint2 *>(gq + u_offset(eu[u]));
 #pragma unroll
         for (int u = 0; u < NB; u++) qb_[u] = *reinterpret_cast<const uint2 *>(gq + b_offset(eb[u]));
+#endif
+#ifdef DESC_EXP_NOPIXELS
+        // timing only: the window is loaded and waited for, no pixel is processed
+        for (int u = 0; u < NA; u++) asm volatile("" :: "v"(qa_[u].x), "v"(qa_[u].y));
+        for (int u = 0; u < NU2; u++) asm volatile("" :: "v"(qu2_[u].x), "v"(qu2_[u].y), "v"(qu2_[u].z), "v"(qu2_[u].w));
+        for (int u = 0; u < NU; u++) asm volatile("" :: "v"(qu_[u].x), "v"(qu_[u].y));
+        for (int u = 0; u < NB; u++) asm volatile("" :: "v"(qb_[u].x), "v"(qb_[u].y));
+#else
 #pragma unroll
         for (int u = 0; u < NA; u++) a_pixels(ea[u], qa_[u]);
 #pragma unroll
@@ -500,6 +538,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GFMT == 0 ? 
         for (int u = 0; u < NU; u++) u_pixels(eu[u], qu_[u]);
 #pragma unroll
         for (int u = 0; u < NB; u++) b_pixels(eb[u], qb_[u]);
+#endif
     };
     auto quad_loops = [&](const char *gq, const char *tq) {
         const QuadRecord R(qa >> 6, qu2 >> 6, qu >> 6, qb >> 6);
@@ -552,6 +591,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GFMT == 0 ? 
     __syncthreads();
 
     // column sums -> fin[bin], bin = circle*8 + a (72..79: overlap)
+#ifndef DESC_EXP_NOREDUCE
     {
         const int cg = lane & 7, rsub = lane >> 3;
 #pragma unroll
@@ -577,6 +617,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GFMT == 0 ? 
             }
         }
     }
+#endif
     __syncthreads();
 
     // main orientation (:110-126): first bin 1..8 with the strictly largest value, 0 if none > 0
