@@ -191,6 +191,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GFMT == 0 ? 
     // holds one band of the gradient plane instead of all of it -- and then the k-th eighth of the
     // padding slots; the workgroups of an XCD stride through its list.
     const int bs = (nfilled + 7) >> 3, pb = (max_kp - nfilled + 7) >> 3;
+#ifdef DESC_EXP_HOIST
+    // timing only: the wave's first keypoint and table record serve all its slots -- no dependent keypoint -> record ->
+    // gather chain after the first slot
+    bool hoisted = false;
+    kp_t kp_keep = {};
+    uint32_t rec_keep[16] = {};
+#endif
     for (int v = blockIdx.x; v < (LOOP ? 8 * (bs + pb) : max_kp); v += LOOP ? (int)gridDim.x : max_kp) {
     int kslot = v;
     if constexpr (LOOP) {
@@ -211,7 +218,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GFMT == 0 ? 
         if (lane < 8) desc[slot * 72 + 64 + lane] = 0;
         continue;
     }
+#ifdef DESC_EXP_HOIST
+    if (!hoisted) kp_keep = kps[slot];
+    const kp_t kp = kp_keep;
+#else
     const kp_t kp = kps[slot];
+#endif
 #ifdef DESC_EXP_EMPTY
     const int px = 0, py = kp.y;                      // timing only: every slot takes the padding path (load, two stores)
 #else
@@ -487,9 +499,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GFMT == 0 ? 
 #ifdef DESC_EXP_FEWER
             if (i == ND / 4 - 1) { rec[4 * i] = rec[0] * 3u; rec[4 * i + 1] = rec[1] * 5u; rec[4 * i + 2] = rec[2] * 7u; rec[4 * i + 3] = rec[3] * 9u; continue; }   // timing only: three table loads
 #endif
+#ifdef DESC_EXP_HOIST
+            if (hoisted) { rec[4 * i] = rec_keep[4 * i]; rec[4 * i + 1] = rec_keep[4 * i + 1]; rec[4 * i + 2] = rec_keep[4 * i + 2]; rec[4 * i + 3] = rec_keep[4 * i + 3]; continue; }
+#endif
             const uint4 v = *reinterpret_cast<const uint4 *>(tq + QuadRecord::at((uint32_t)lane, (uint32_t)i * 16u));
             rec[4 * i] = v.x; rec[4 * i + 1] = v.y; rec[4 * i + 2] = v.z; rec[4 * i + 3] = v.w;
+#ifdef DESC_EXP_HOIST
+            rec_keep[4 * i] = v.x; rec_keep[4 * i + 1] = v.y; rec_keep[4 * i + 2] = v.z; rec_keep[4 * i + 3] = v.w;
+#endif
         }
+#ifdef DESC_EXP_HOIST
+        hoisted = true;
+#endif
         auto half = [&](int byteofs) { return (byteofs & 2) ? rec[byteofs >> 2] >> 16 : rec[byteofs >> 2]; };   // the fields' masks drop a low half's upper bits
 #pragma unroll
         for (int u = 0; u < NA; u++) ea[u] = make_uint2(rec[2 * u], rec[2 * u + 1]);
