@@ -601,6 +601,10 @@ def main():
                 shares = {"valu issue": r["valu_issue_frac_at_sustained_clock"], "matrix cores": r.get("mfma_busy_frac", 0.0),
                           "LDS instruction path": r.get("lds_issue_frac_at_sustained_clock", 0.0)}
                 r["binds"] = max(shares, key=shares.get)
+                if k == "k_describe":
+                    # the shares are model figures (4 cycles per instruction); timing-only ablations say what they are worth
+                    r["ablations"] = ("DESIGN.md 6.0: gather path alone 2.62 ms, VALU path alone 2.16 - 2.31 ms, whole kernel 2.39 ms per "
+                                      "256 frames; without any ds_add 2.32 ms -- balanced, no single path binds")
                 return r
             def roof_blur_mfma():
                 """k_blur runs on the matrix cores: its bound is MFMA issue, not HBM.  `achieved` counts the
