@@ -544,6 +544,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GFMT == 0 ? 
 #pragma unroll
         for (int u = 0; u < NB; u++) qb_[u] = *reinterpret_cast<const uint2 *>(gq + b_offset(eb[u]));
 #endif
+#ifdef DESC_EXP_EXTRAVALU
+        {   // timing only: 64 more VALU instructions per slot (four independent chains of v_and_or_b32), no other work
+            uint32_t x0 = rec[0], x1 = rec[1], x2 = rec[2], x3 = rec[3];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x0) : "v"(x1), "v"(x2));
+                asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x1) : "v"(x2), "v"(x3));
+                asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x2) : "v"(x3), "v"(x0));
+                asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x3) : "v"(x0), "v"(x1));
+            }
+            asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+        }
+#endif
 #ifdef DESC_EXP_NOPIXELS
         // timing only: the window is loaded and waited for, no pixel is processed
         for (int u = 0; u < NA; u++) asm volatile("" :: "v"(qa_[u].x), "v"(qa_[u].y));
