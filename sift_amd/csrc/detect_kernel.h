@@ -327,12 +327,16 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
     };
 
     // prologue: rows ys-1 (slot 0) and ys (slot 1)
-    uint4 Q, Qh, Qn, Qhn;
+    // Rows are requested two iterations ahead into two request slots that alternate (no register is copied, so no
+    // wait is forced early): the kernel is bound by the memory system, and the second row in flight is worth 2.2 %
+    // (0.922 -> 0.901 ms per 256 frames).  In round 1, when VALU issue bound it, deeper requests were 1.3 % slower.
+    uint4 Q, Qh, Qs[2], Qhs[2];
     load_row(ys - 1, Q, Qh);
     push(Q, Qh, 0);
     load_row(ys, Q, Qh);
     push(Q, Qh, 1);
-    load_row(ys + 1, Qn, Qhn);
+    load_row(ys + 1, Qs[0], Qhs[0]);
+    load_row(ys + 2, Qs[1], Qhs[1]);
 
     uint2 gb0 = make_uint2(0u, 0u), gb1 = gb0, gb2 = gb0;   // gradient words of rows 4k .. 4k+2 until row 4k+3 is done
     uint32_t qcount = 0;                              // wave-uniform
@@ -365,12 +369,11 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
     const h2 thh = h2_sub(thbits | thbits << 16, 0x64006400u);                                          // ... - 1024, both halves
     const u64 colmask = __ballot(colvalid);
     // one image row; A, B, C = slots of rows y-1, y, y+1 (C is overwritten with row y+1)
-    auto row = [&](int y, auto ka, auto kb, auto kc) {
+    auto row = [&](int y, auto ka, auto kb, auto kc, auto ls) {
         constexpr int A = decltype(ka)::value, B = decltype(kb)::value, C = decltype(kc)::value;
-        Q = Qn; Qh = Qhn;                                                // row y+1
-        load_row(y + 2, Qn, Qhn);                                        // prefetch (a row past the strip is harmless; requesting rows
-                                                                         // three iterations ahead was measured: 1.3 % slower)
-        push(Q, Qh, C);
+        constexpr int LS = decltype(ls)::value;                          // request slot that holds row y+1
+        push(Qs[LS], Qhs[LS], C);                                        // row y+1, requested two iterations ago
+        load_row(y + 3, Qs[LS], Qhs[LS]);                                // (a row past the strip is harmless)
 
         // Neighbourhood maximum of a pixel (the 26 values of :245-304): its own column without the centre,
         // Y = max(e[y], m[y-1], m[y+1]), and the whole columns left and right of it, X = max(m[y-1], m[y], m[y+1]);
@@ -488,10 +491,14 @@ __global__ __launch_bounds__(64) void k_detect(const uint4 *__restrict__ pyr,
         using K1 = std::integral_constant<int, 1>;
         using K2 = std::integral_constant<int, 2>;
         // (qcap is DETECT_QUEUE except in the test that forces drains, sift_hip_set_detect_queue)
-        for (int y = ys; y < ye; y += 3) {
-            row(y, K0{}, K1{}, K2{});
-            if (y + 1 < ye) row(y + 1, K1{}, K2{}, K0{});
-            if (y + 2 < ye) row(y + 2, K2{}, K0{}, K1{});
+        // the row slots rotate with period 3, the request slots with period 2: six bodies
+        for (int y = ys; y < ye; y += 6) {
+            row(y, K0{}, K1{}, K2{}, K0{});
+            if (y + 1 < ye) row(y + 1, K1{}, K2{}, K0{}, K1{});
+            if (y + 2 < ye) row(y + 2, K2{}, K0{}, K1{}, K0{});
+            if (y + 3 < ye) row(y + 3, K0{}, K1{}, K2{}, K1{});
+            if (y + 4 < ye) row(y + 4, K1{}, K2{}, K0{}, K0{});
+            if (y + 5 < ye) row(y + 5, K2{}, K0{}, K1{}, K1{});
         }
     }
 
