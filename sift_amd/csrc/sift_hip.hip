@@ -462,7 +462,11 @@ int run_detect(sift_hip_ctx *c, const uint8_t *d_imgs, int nframes, uint32_t *d_
         const int waves = (NB * nstrips + 15) / 16;
         // workgroups of two unit groups (two waves of each role; two workgroups fill a CU's register file):
         // measured against one and four groups per workgroup, 1.42 - 1.49 ms against 1.52 and 1.54 - 1.61 per 256 frames
-        hipLaunchKernelGGL(sift::k_blur_mfma, dim3((waves + BLUR_MFMA_WG_GROUPS - 1) / BLUR_MFMA_WG_GROUPS, nframes), dim3(128 * BLUR_MFMA_WG_GROUPS), 0, s, d_imgs, c->d_pyr, W, H, rows, nstrips, c->Wl);
+        // batches of 64 frames and more: every XCD takes whole frames (k_blur_mfma, xcd_frames); the grid's frame
+        // dimension is rounded up to a multiple of 8 and the workgroups of the frames that do not exist return at once
+        const int xcd_frames = nframes >= 64 ? nframes : 0;
+        const int gy = xcd_frames ? (nframes + 7) / 8 * 8 : nframes;
+        hipLaunchKernelGGL(sift::k_blur_mfma, dim3((waves + BLUR_MFMA_WG_GROUPS - 1) / BLUR_MFMA_WG_GROUPS, gy), dim3(128 * BLUR_MFMA_WG_GROUPS), 0, s, d_imgs, c->d_pyr, W, H, rows, nstrips, c->Wl, xcd_frames);
     } else {
         StageTimer t(c, ST_BLUR, s);
         const int rows = pick_blur_rows(c, nframes);

@@ -611,6 +611,37 @@ def test_bench_shape_against_the_oracle(sift, orc):
             assert nsum > 9000 * nb                                     # dense frames, as in the bench
 
 
+def test_batches_dealt_to_xcds_by_frame(sift, orc):
+    """Batches of 64 frames and more: k_blur_mfma's workgroups are remapped so that every XCD takes whole frames, and
+    the grid's frame dimension is rounded up to a multiple of 8.  67 frames (three of the 72 frame slots of the
+    grid do not exist) and 64 frames of 324 x 201 (a width that is no multiple of 8 pixels' units) against the oracle,
+    frame by frame; the same frames in one call of 63 (the plain mapping) must give the same arrays."""
+    import torch
+    W, H, K = 324, 201, 10000
+    B = 67
+    imgs = np.stack([orc.synth_frame(100 + s, W, H) for s in range(B)])
+    ref = _oracle_frames(orc, imgs)
+    with sift.SiftContext(W, H, max_batch=B) as ctx:
+        d_img = torch.from_numpy(imgs).cuda()
+        outs = {}
+        for nb in (67, 64, 63):
+            d_kps = torch.full((nb, K, 2), -1, dtype=torch.int32, device="cuda")
+            d_desc = torch.full((nb, K, 72), -1, dtype=torch.int32, device="cuda")
+            d_tot = torch.full((nb,), -1, dtype=torch.int32, device="cuda")
+            ctx.detect_and_compute_dev(d_img, nb, d_kps, d_desc, d_tot)
+            ctx.sync()
+            kps = d_kps.cpu().numpy().view(sift.KP_DTYPE).reshape(nb, K)
+            desc = d_desc.cpu().numpy().view(np.uint32)
+            tot = d_tot.cpu().numpy()
+            for b in range(nb):
+                rk, rd, total = ref[b]
+                n = nvalid(rk)
+                assert (kps[b] == rk).all(), "keypoints of frame %d of %d" % (b, nb)
+                assert (desc[b, :n] == rd[:n]).all() and not desc[b, n:].any() and int(tot[b]) == total, (b, nb)
+            outs[nb] = (kps, desc)
+        assert (outs[67][0][:63] == outs[63][0]).all() and (outs[67][1][:63] == outs[63][1]).all()
+
+
 def test_detect_queue_drains_in_mid_strip(sift, orc):
     """k_detect queues the pixels that pass the extremum and contrast tests in LDS and drains the
     queue when the next rows might not fit (a strict maximum and a strict minimum may be neighbours,
