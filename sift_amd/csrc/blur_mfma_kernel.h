@@ -299,7 +299,6 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
     const uint32_t gmask = inside >= 4 ? ~0u : inside <= 0 ? 0u : (1u << (8 * inside)) - 1u;
 
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     // Offsets are plain 32-bit arithmetic, no selects: a row above the image gives a "negative" offset, i.e.
     // one near 2^32, a row below it one at or beyond the frame's size, and the bounds check answers both with
     // zeros; lanes without a valid chunk (units past the last one, chunks right of the row) read somewhere
@@ -382,43 +381,48 @@ __device__ __forceinline__ void blur_mfma_role(const uint8_t *__restrict__ imgs,
         BlurState<1> s1;
         load_frags<2>(s2, lane);
         load_frags<1>(s1, lane);
-        uint32_t d1[LAG] = {0, 0};
+        constexpr int SLAG = DMAX / 2;                                  // the source pixels of a G2 pair entered SLAG steps before it is finished
+        static_assert(SLAG == 3, "delay line of the source dwords");
+        uint32_t d1[LAG] = {0, 0}, sq[SLAG] = {0, 0, 0};
         const int n = npairs + DMAX;
         uint32_t roff = (uint32_t)((ys - DMAX + rb) * W) + (colok ? (uint32_t)(col0 + 4 * sh) : 0u);
-        uint32_t srcoff = (uint32_t)((ys - 2 * DMAX + rb) * W) + 4u * (uint32_t)q;   // source dword of the row finished by the step requested next
         uint32_t soff = ((uint32_t)((ys - 2 * DMAX + rb) * W4) + (uint32_t)q) * 16u;
         uint32_t rel = (uint32_t)(rb - 2 * DMAX);
         u32x4 R[AHEAD];
-        uint32_t S[AHEAD];
 #pragma unroll
         for (int k = 0; k < AHEAD; k++) {
             R[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)roff, 0, 0);
-            S[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)srcoff, 0, 0);
             roff += W2;
-            srcoff += W2;
         }
 #pragma unroll
-        for (int k = 0; k < AHEAD; k++) { use_now(R[k]); use_now(S[k]); }
+        for (int k = 0; k < AHEAD; k++) use_now(R[k]);
+        typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
         auto body = [&](auto slot) {
             constexpr int k = decltype(slot)::value;
             const v4i P = operand(R[k]);
-            // the G2 pair (i - 6, i - 5) and the G1 pair (i - 2, i - 1) are finished by this step.  The source dword
-            // leaves first, from the register its load wrote, before that register is requested again (as part of one
-            // 12-byte store it would need a copy into a register next to the others, and the copy would wait for a
-            // load that has only just been issued)
-            const uint32_t so = rel < len ? BLUR_SOFF(soff) : OUTSIDE;
-            __builtin_amdgcn_raw_buffer_store_b32(S[k], ws, (int)so, 0, BLUR_STORE_AUX);
+            // The lane's own four source pixels are part of its operand chunk: the chunk of an even half (g & 1 = 0)
+            // starts 12 pixels left of the unit, so they are its last dword; that of an odd half starts at the
+            // unit's fifth pixel, so they are its first.  No separate load of the source plane: the dword waits in a
+            // delay line until the G2 pair of its rows is finished, and {src, G1, G2} leave as ONE 12-byte store.
+            uint32_t src_now = (uint32_t)((g & 1) ? P[0] : P[3]) ^ 0x80808080u;
+            use_now(src_now);                                          // formed here, before the slot is requested again: left to the
+                                                                       // compiler the request lands in another register, is copied at the
+                                                                       // loop's end, and the copy waits for a load that has only just left
             R[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)roff, 0, 0);
-            S[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)srcoff, 0, 0);
             roff += W2;
-            srcoff += W2;
             slide_mfma<2>(s2, P);
             slide_mfma<1>(s1, P);
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{d1[LAG - 1] & gmask, finished_row<2>(s2) & gmask}, ws, (int)so, 4, BLUR_STORE_AUX);   // scalar offset 4: the G1 and G2 dwords
+            // the G2 pair (i - 6, i - 5) and the G1 pair (i - 2, i - 1) are finished by this step
+            const uint32_t so = rel < len ? BLUR_SOFF(soff) : OUTSIDE;
+            // (as a 4-byte and an 8-byte store the same data takes 1.107 ms per 256 frames, as one 12-byte store 1.029)
+            __builtin_amdgcn_raw_buffer_store_b96(u32x3{sq[SLAG - 1], d1[LAG - 1] & gmask, finished_row<2>(s2) & gmask}, ws, (int)so, 0, BLUR_STORE_AUX);
             soff += 4u * W2;                                           // two rows of W4 groups of 16 bytes
             rel += 2u;
             d1[1] = d1[0];
             d1[0] = finished_row<1>(s1);
+            sq[2] = sq[1];
+            sq[1] = sq[0];
+            sq[0] = src_now;
         };
         for (int t = 0; t < n; t += AHEAD)
             static_for<0, AHEAD>([&](auto slot) { body(slot); });
