@@ -182,7 +182,7 @@ static_assert(frags_hold_the_table<1>() && frags_hold_the_table<2>() && frags_ho
 #define BLUR_MFMA_WAVES 2
 #endif
 #ifndef BLUR_MFMA_AHEAD
-#define BLUR_MFMA_AHEAD 2
+#define BLUR_MFMA_AHEAD 3
 #endif
 template <int WHICH> constexpr int blur_init() { return 16384 + 128 * (int)ksum<WHICH>(); }
 
